@@ -1,0 +1,168 @@
+/*
+ * pcamv_gpu.h -- C ABI of the MI355X P-frame analysis + MV-steganography library
+ *                (libpcamv_gpu.so, built from video-steganography-pcamv_amd/csrc/).
+ *
+ * Frame-granular replacement for the per-macroblock work the reference does inside
+ * x264_slice_write() (encoder/encoder.c:1176-2011) on the first of its two passes over a
+ * P frame:
+ *
+ *   entry point                 replaces (reference file:line)
+ *   --------------------------  -----------------------------------------------------------
+ *   pcamv_gpu_open              vtable + table set-up in x264_encoder_open, encoder.c:694-766
+ *                               (x264_cqm_init common/set.c:68, cost tables analyse.c:193-229)
+ *   pcamv_gpu_set_ref           x264_fdec_filter_row's plane production, encoder.c:1038-1047:
+ *                               x264_frame_expand_border (common/frame.c:246),
+ *                               x264_frame_filter/hpel_filter (common/mc.c:453,167),
+ *                               x264_frame_expand_border_filtered (common/frame.c:275)
+ *   pcamv_gpu_upload_fenc       x264_frame_copy_picture (common/frame.c:183-220)
+ *   pcamv_gpu_analyse_pframe    pass 1 of the raster MB loop, encoder.c:1240-1273:
+ *                               x264_macroblock_cache_load (common/macroblock.c:914),
+ *                               x264_macroblock_analyse (encoder/analyse.c:2555-3697) incl.
+ *                               x264_me_search_ref (encoder/me.c:158), refine_subpel (me.c:715),
+ *                               x264_ih_get_mv_cost (analyse.c:2391) and the pass-1 record
+ *                               (analyse.c:3518-3689); the pass-1 x264_macroblock_encode
+ *                               (encoder/macroblock.c:484) reconstruction
+ *   pcamv_gpu_embed_pframe      cover/cost assembly + message + stc_embed + flip map,
+ *                               encoder.c:1561-1855, embed.h:309-548
+ *   pcamv_gpu_stc_extract       (no reference counterpart: extractor defined in SURVEY 8(c))
+ *   pcamv_gpu_close             x264_encoder_close's frees
+ *
+ * All functions return 0 on success and a negative PCAMV_E* code on error; the message is
+ * available from pcamv_gpu_last_error().  One context per encoder, not re-entrant (the
+ * reference's embedding path is single-threaded).  The caller owns every host
+ * buffer it passes; the context owns all device memory.  There is NO CPU fallback: without a
+ * HIP device every entry point fails with PCAMV_ENODEV.
+ */
+#ifndef PCAMV_GPU_H
+#define PCAMV_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCAMV_EINVAL  (-1)
+#define PCAMV_ENODEV  (-2)
+#define PCAMV_ENOMEM  (-3)
+#define PCAMV_EHIP    (-4)
+#define PCAMV_EUNSUP  (-5)
+
+/* enum values are the reference's own (x264.h:106-111, common/macroblock.h mb_class_e / mb_partition_e) */
+enum { PCAMV_ME_DIA = 0, PCAMV_ME_HEX = 1, PCAMV_ME_UMH = 2, PCAMV_ME_ESA = 3, PCAMV_ME_TESA = 4 };
+enum { PCAMV_P_L0 = 4, PCAMV_P_8x8 = 5, PCAMV_P_SKIP = 6 };
+enum { PCAMV_D_L0_4x4 = 0, PCAMV_D_L0_8x4 = 1, PCAMV_D_L0_4x8 = 2, PCAMV_D_L0_8x8 = 3,
+       PCAMV_D_8x8 = 13, PCAMV_D_16x8 = 14, PCAMV_D_8x16 = 15, PCAMV_D_16x16 = 16 };
+#define PCAMV_ANALYSE_PSUB16x16 0x0010u   /* x264.h:99  */
+#define PCAMV_ANALYSE_PSUB8x8   0x0020u   /* x264.h:100 */
+
+/* The subset of x264_param_t (x264.h:154-311) this path reads, with the reference's field
+ * names and its post-x264_validate_parameters meaning (encoder.c:342-613). */
+typedef struct pcamv_params_t {
+    int32_t i_width, i_height;        /* luma size, multiples of 16                              */
+    int32_t i_me_method;              /* analyse.i_me_method  (PCAMV_ME_*)                       */
+    int32_t i_me_range;               /* analyse.i_me_range   (default 16, common.c:121)         */
+    int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..5 here (>=6 needs RDO: next)*/
+    int32_t i_mv_range;               /* analyse.i_mv_range after level lookup, encoder.c:558    */
+    int32_t b_chroma_me;              /* analyse.b_chroma_me  (default 1)                        */
+    int32_t b_fast_pskip;             /* analyse.b_fast_pskip (default 1)                        */
+    int32_t b_dct_decimate;           /* analyse.b_dct_decimate (default 1)                      */
+    int32_t b_cabac;                  /* b_cabac (default 1): only the P8x8 ref-cost term        */
+    uint32_t inter;                   /* analyse.inter & (PSUB16x16|PSUB8x8)                     */
+    int32_t i_chroma_qp_offset;       /* analyse.i_chroma_qp_offset                              */
+    int32_t i_luma_deadzone[2];       /* analyse.i_luma_deadzone {inter,intra} = {21,11}         */
+    int32_t i_tscale;                 /* temporal-candidate scale (common/macroblock.c:454); 256
+                                         for consecutive P frames, 0 = previous frame was intra  */
+} pcamv_params_t;
+
+/* One macroblock of the pass-1 record: same members, order of blocks and meaning as
+ * h->info.cache[] (common/common.h:585-603).  mv[] / ref[] use x264's block-index order
+ * 0 1 4 5 / 2 3 6 7 / 8 9 12 13 / 10 11 14 15 (analyse.c:2893-2898). */
+typedef struct pcamv_mb_t {
+    int32_t i_type;                   /* PCAMV_P_L0 | PCAMV_P_8x8 | PCAMV_P_SKIP                 */
+    int32_t i_partition;              /* PCAMV_D_16x16 | 16x8 | 8x16 | 8x8                       */
+    int32_t i_qp;
+    uint8_t i_sub_partition[4];
+    int8_t  ref[16];
+    int16_t mv[16][2];
+    int16_t mv_stego[16][2];
+    int32_t inter_stego_cost[16];
+    int16_t pskip_mv[2];              /* pskip_mv_ (encoder.c:1265)                              */
+    int16_t mvr16[2];                 /* h->mb.mvr[0][0][mb]: the 16x16 search result            */
+    uint8_t used;
+    uint8_t pad[3];
+} pcamv_mb_t;
+
+/* Per-frame embedding vectors (h->info.cover/rho_final/message/stego/filp, common.h:604-617).
+ * The caller allocates each array with room for 16 * mb_count entries. */
+typedef struct pcamv_embed_t {
+    int32_t  n;                       /* number of carrier MVs (h->info.length)                  */
+    int32_t  m;                       /* number of message bits embedded                         */
+    int32_t  stc_ok;                  /* stc_embed return value (ignored by the reference)       */
+    int32_t  num_flip;
+    uint8_t *cover;
+    float   *rho;
+    uint8_t *message;
+    uint8_t *stego;
+    int8_t  *flip;
+} pcamv_embed_t;
+
+typedef struct pcamv_ctx pcamv_ctx_t;
+
+int  pcamv_gpu_open(const pcamv_params_t *param, int device, pcamv_ctx_t **ctx);
+void pcamv_gpu_close(pcamv_ctx_t *ctx);
+const char *pcamv_gpu_last_error(const pcamv_ctx_t *ctx);
+
+/* Source picture, I420, caller-owned host planes. */
+int pcamv_gpu_upload_fenc(pcamv_ctx_t *ctx, const uint8_t *const plane[3], const int stride[3]);
+
+/* Reconstructed reference picture (already deblocked by the caller), I420 host planes, plus
+ * the previous frame's final motion field for the temporal candidates
+ * (x264_mb_predict_mv_ref16x16, common/macroblock.c:444-467): prev_mv is [mb_h*4][mb_w*4][2]
+ * quarter-pel, prev_ref is [mb_h*2][mb_w*2]; both NULL when the reference is an I frame.
+ * Produces the padded full/H/V/HV luma planes and padded chroma on the device. */
+int pcamv_gpu_set_ref(pcamv_ctx_t *ctx, const uint8_t *const plane[3], const int stride[3],
+                      const int16_t *prev_mv, const int8_t *prev_ref);
+
+/* Read back the 4 padded luma planes produced by set_ref: out must hold 4*stride*lines
+ * bytes; *stride = ALIGN(width+64,16), *lines = height+64, origin at (32,32). */
+int pcamv_gpu_get_ref_planes(pcamv_ctx_t *ctx, uint8_t *out, int *stride, int *lines);
+
+/* Pass-1 analysis of the whole P frame at luma QP qp.  out_mb[mb_count] receives the record
+ * (with embed != 0 also used / mv_stego / inter_stego_cost).  recon[3] (optional, tightly
+ * packed w*h, w/2*h/2 x2) receives the pass-1 reconstruction before deblocking. */
+int pcamv_gpu_analyse_pframe(pcamv_ctx_t *ctx, int qp, int embed, pcamv_mb_t *out_mb,
+                             uint8_t *const recon[3]);
+
+/* Embedding stage on the records of the last analyse call.  emrate as x264's --emrate
+ * (encoder.c:1828-1836): 0 < r <= 1 bits per MV, r > 1 bits per frame.  message == NULL
+ * draws the bits from the context's glibc-compatible rand() stream (seed 1 at open, as the
+ * reference never calls srand, encoder.c:1838-1840); otherwise message[0..m) is used. */
+int pcamv_gpu_embed_pframe(pcamv_ctx_t *ctx, float emrate, const uint8_t *message, int message_len,
+                           pcamv_embed_t *out);
+
+/* Apply the flip map to the record (pass-2 substitution, analyse.c:3001-3107): final MVs. */
+int pcamv_gpu_final_mvs(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb);
+
+/* Syndrome-trellis extraction (host side of the BER check): stego bits -> message bits. */
+int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int matrixheight, uint8_t *message);
+
+/* Device-resident variants used by bench.py and the multi-frame pipeline: planes are raw
+ * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */
+int pcamv_gpu_set_ref_device(pcamv_ctx_t *ctx, const void *y, const void *u, const void *v,
+                             const void *prev_mv, const void *prev_ref);
+int pcamv_gpu_set_fenc_device(pcamv_ctx_t *ctx, const void *y, const void *u, const void *v);
+/* One full step on resident inputs: plane production + analysis + RCA + embedding; results
+ * stay on the device until pcamv_gpu_fetch_results. stream = hipStream_t as void*. */
+int pcamv_gpu_step_device(pcamv_ctx_t *ctx, int qp, float emrate, void *stream);
+int pcamv_gpu_fetch_results(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb, pcamv_embed_t *out);
+/* Average duration in ms of the dominant kernel over the launches since the last reset,
+ * measured with hipEvents on the launch stream (bench.py roofline). */
+int pcamv_gpu_kernel_time(pcamv_ctx_t *ctx, const char *kernel, double *avg_ms, int *launches, int reset);
+
+int pcamv_gpu_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

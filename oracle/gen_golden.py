@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/*.npz from the reference's own code (oracle/_ref/libpcamv_ref.so).
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference was present to build the library
+(oracle/Makefile `make ref`).  Each fixture stores the inputs (I420 planes, previous motion
+field, parameters) and what the reference computed for them: the pass-1 record of every MB
+(type, partition, MVs, replacement MVs, RCA costs), the pass-1 reconstruction and SHA-256 of
+the produced half-pel planes.  Fixtures are data only: no reference text is stored.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "video-steganography-pcamv_amd"))
+import refh  # noqa: E402
+import orc  # noqa: E402  (only for level_mv_range / block tables, no oracle compute)
+from pcamv_amd.synth import make_clip  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+BX = [0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3]
+BY = [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def mv_field(mbs, mbw, mbh):
+    mvf = np.zeros((mbh * 4, mbw * 4, 2), np.int16)
+    for xy in range(mbw * mbh):
+        my, mx = divmod(xy, mbw)
+        for i in range(16):
+            mvf[my * 4 + BY[i], mx * 4 + BX[i]] = mbs["mv"][xy][i]
+    return mvf, np.zeros((mbh * 2, mbw * 2), np.int8)
+
+
+def analysis_fixture(name, W, H, me, subme, qp, inter, seed, static_cols, me_range=16, noise=6, frames=2):
+    clip = make_clip(W, H, frames + 1, seed=seed, static_cols=static_cols, noise=noise)
+    mvr = orc.level_mv_range(W, H)
+    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, embed=1, inter_flags=inter | 0x1 | 0x100, me_range=me_range)
+    ref, prev = clip[0], None
+    d = dict(width=W, height=H, me=refh.ME[me], subme=subme, qp=qp, inter=inter, mv_range=mvr, me_range=me_range, frames=frames)
+    for t in range(1, frames + 1):
+        if prev is None:
+            r.set_ref(*ref)
+        else:
+            r.set_ref(*ref, prev_mv=prev[0], prev_ref=prev[1])
+        r.set_fenc(*clip[t])
+        planes, integ = r.ref_planes(want_integral=me in ("esa", "tesa"))
+        mbs, rec = r.analyse_pframe()
+        for k, nm in enumerate("yuv"):
+            d[f"f{t}_ref_{nm}"] = ref[k]
+            d[f"f{t}_fenc_{nm}"] = clip[t][k]
+            d[f"f{t}_rec_{nm}"] = rec[k]
+        if prev is not None:
+            d[f"f{t}_prev_mv"], d[f"f{t}_prev_ref"] = prev
+        d[f"f{t}_mbs"] = mbs
+        d[f"f{t}_plane_sha"] = np.array([sha(planes[k]) for k in range(4)])
+        # interior + filtered margin of the integral plane is what the search can touch
+        if integ is not None:
+            d[f"f{t}_integral_sha"] = np.array([sha(integ[24:H + 32 - 8, 24:W + 32 - 8])])
+        prev = mv_field(mbs, W // 16, H // 16)
+        ref = rec
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    types = np.bincount(mbs["type"], minlength=7)[4:]
+    print(name, "types L0/8x8/skip", types.tolist())
+
+
+def primitive_fixture():
+    rng = np.random.default_rng(2024)
+    r = refh.Ref(176, 144, embed=0)
+    L = refh.lib()
+    import ctypes as C
+    d = {}
+    a = rng.integers(0, 256, (64, 32, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (64, 32, 48), dtype=np.uint8)
+    a[0] = 255; b[0] = 0; a[1] = 0; b[1] = 255          # checkasm's overflow patterns (tools/checkasm.c)
+    a[2, ::2] = 255; a[2, 1::2] = 0; b[2, ::2] = 0; b[2, 1::2] = 255
+    res = np.zeros((3, 7, 64), np.int32)
+    for k, fn in enumerate((L.refh_sad, L.refh_satd, L.refh_ssd)):
+        for ip in range(7):
+            for i in range(64):
+                res[k, ip, i] = fn(r.ctx, ip, a[i].ctypes.data_as(C.c_void_p), 32, b[i].ctypes.data_as(C.c_void_p), 48)
+    d.update(pix_a=a, pix_b=b, pix_res=res)
+    # qpel MC out of the four reference planes + chroma MC
+    clip = make_clip(176, 144, 1, seed=3)
+    r.set_ref(*clip[0])
+    planes, _ = r.ref_planes()
+    st = planes.shape[2]
+    mvs = rng.integers(-40, 40, (96, 2)).astype(np.int32)
+    szs = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4), (20, 16), (16, 17)]
+    outs = []
+    for i, (mx, my) in enumerate(mvs):
+        w, h = szs[i % len(szs)]
+        dst = np.zeros((h, w), np.uint8)
+        src = (C.c_void_p * 4)(*[planes[k].ctypes.data + (32 + 48) * st + 32 + 64 for k in range(4)])
+        L.refh_mc_luma(r.ctx, dst.ctypes.data_as(C.c_void_p), w, src, st, int(mx), int(my), w, h)
+        outs.append(dst.tobytes())
+    d.update(mc_ref=np.stack(clip[0][0:1]), mc_mvs=mvs, mc_out=np.frombuffer(b"".join(outs), np.uint8),
+             mc_u=clip[0][1], mc_v=clip[0][2])
+    cu = np.ascontiguousarray(np.pad(clip[0][1], 16, mode="edge"))
+    outs = []
+    for i, (mx, my) in enumerate(mvs):
+        w, h = szs[i % 7][0] // 2, szs[i % 7][1] // 2
+        dst = np.zeros((h, w), np.uint8)
+        L.refh_mc_chroma(r.ctx, dst.ctypes.data_as(C.c_void_p), w, C.c_void_p(cu.ctypes.data + (16 + 24) * cu.shape[1] + 16 + 32),
+                         cu.shape[1], int(mx), int(my), w, h)
+        outs.append(dst.tobytes())
+    d.update(mcc_out=np.frombuffer(b"".join(outs), np.uint8))
+    d["cost_mv_sha"] = np.array([sha(refh.cost_mv_table(q)[0]) for q in range(52)])
+    # syndrome-trellis known answers
+    for i, (n, m) in enumerate([(125, 60), (284, 142), (541, 35), (1000, 500), (4096, 1000), (6336, 3168), (33, 3)]):
+        cover = rng.integers(0, 2, n).astype(np.uint8); msg = rng.integers(0, 2, m).astype(np.uint8)
+        rho = rng.integers(1, 3000, n).astype(np.float32)
+        if i == 2:
+            rho[::7] = rho[1::7]          # price ties
+        ok, stego = refh.stc_embed(cover, msg, rho)
+        d[f"stc{i}_cover"], d[f"stc{i}_msg"], d[f"stc{i}_rho"], d[f"stc{i}_stego"], d[f"stc{i}_ok"] = cover, msg, rho, stego, np.int32(ok)
+    d["stc_count"] = np.int32(7)
+    # stand-alone motion searches (all 7 block sizes x 5 methods) through x264_me_search_ref
+    clip = make_clip(176, 144, 2, seed=9)
+    cases = []
+    for me in ("dia", "hex", "umh", "esa", "tesa"):
+        for subme in (1, 2, 5):
+            rr = refh.Ref(176, 144, qp=28, me=me, subme=subme, mv_range=64, embed=0, inter_flags=0x131)
+            rr.set_ref(*clip[0]); rr.set_fenc(*clip[1])
+            for pix, (xo, yo) in (("16x16", (0, 0)), ("16x8", (0, 8)), ("8x16", (8, 0)), ("8x8", (8, 8)),
+                                  ("8x4", (0, 4)), ("4x8", (4, 0)), ("4x4", (12, 12))):
+                for (mbx, mby) in ((0, 0), (5, 4), (10, 8)):
+                    mvp = rng.integers(-24, 24, 2).astype(np.int16)
+                    nmvc = int(rng.integers(0, 4))
+                    mvc = rng.integers(-30, 30, (max(nmvc, 1), 2)).astype(np.int16)[:nmvc]
+                    mv, cost = rr.me_search(28, mbx, mby, pix, xo, yo, mvp, mvc if nmvc else np.zeros((0, 2), np.int16))
+                    row = [refh.ME[me], subme, refh.PIXEL[pix], xo, yo, mbx, mby, mvp[0], mvp[1], nmvc]
+                    row += list(np.pad(mvc.ravel(), (0, 6 - 2 * nmvc))) + [mv[0], mv[1], cost[0], cost[1]]
+                    cases.append(row)
+    d["me_cases"] = np.array(cases, np.int32)
+    for k, nm in enumerate("yuv"):
+        d[f"me_ref_{nm}"] = clip[0][k]; d[f"me_fenc_{nm}"] = clip[1][k]
+    np.savez_compressed(os.path.join(OUT, "primitives.npz"), **d)
+    print("primitives: me cases", len(cases))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    if not refh.available():
+        sys.exit("oracle/_ref/libpcamv_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    primitive_fixture()
+    analysis_fixture("qcif_hex_subme5", 176, 144, "hex", 5, 26, 0x10, 5, 48)
+    analysis_fixture("qcif_dia_subme2", 176, 144, "dia", 2, 22, 0x10, 9, 0)
+    analysis_fixture("qcif_umh_subme4_psub8", 176, 144, "umh", 4, 30, 0x30, 8, 32)
+    analysis_fixture("qcif_esa_subme3", 176, 144, "esa", 3, 26, 0x10, 6, 32)
+    analysis_fixture("qcif_tesa_subme5_psub8", 176, 144, "tesa", 5, 28, 0x30, 4, 48)
+    analysis_fixture("qcif_hex_noisy_partitions", 176, 144, "hex", 5, 26, 0x10, 5, 0, noise=40)
+    analysis_fixture("cif_umh_subme5", 352, 288, "umh", 5, 26, 0x10, 7, 64)

@@ -238,13 +238,16 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
             x264_macroblock_analyse(h);
             x264_macroblock_encode(h);
             o->type = h->mb.i_type; o->partition = h->mb.i_partition; o->qp = h->mb.i_qp;
-            memcpy(o->sub_partition, h->mb.i_sub_partition, 4);
+            /* i_sub_partition is stale outside P_8x8 and mvr is never written for an early P_SKIP
+             * (analyse.c:1170-1177 returns first): report neutral values for those don't-cares */
+            if (h->mb.i_type == P_8x8) memcpy(o->sub_partition, h->mb.i_sub_partition, 4);
+            else memset(o->sub_partition, D_L0_8x8, 4);
             for (int i = 0; i < 16; i++) {
                 o->ref[i] = h->mb.cache.ref[0][x264_scan8[i]];
                 o->mv[i][0] = h->mb.cache.mv[0][x264_scan8[i]][0];
                 o->mv[i][1] = h->mb.cache.mv[0][x264_scan8[i]][1];
             }
-            o->mvr16[0] = h->mb.mvr[0][0][mb_xy][0]; o->mvr16[1] = h->mb.mvr[0][0][mb_xy][1];
+            if (h->mb.i_type != P_SKIP) { o->mvr16[0] = h->mb.mvr[0][0][mb_xy][0]; o->mvr16[1] = h->mb.mvr[0][0][mb_xy][1]; }
             if (embed) {
                 o->used = h->info.cache[mb_xy].used;
                 memcpy(o->mv_stego, h->info.cache[mb_xy].mv_stego, sizeof(o->mv_stego));

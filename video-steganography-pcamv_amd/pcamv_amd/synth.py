@@ -19,8 +19,11 @@ def _blur5(a, passes):
     return a
 
 
-def make_clip(width, height, frames, seed=7, noise=6):
-    """Return a list of (Y, U, V) uint8 arrays of shape (h, w), (h/2, w/2), (h/2, w/2)."""
+def make_clip(width, height, frames, seed=7, noise=6, static_cols=0):
+    """Return a list of (Y, U, V) uint8 arrays of shape (h, w), (h/2, w/2), (h/2, w/2).
+
+    static_cols > 0 keeps that many left-hand columns (a multiple of 16) motionless and
+    noise-free, which is what produces P_SKIP macroblocks."""
     rng = np.random.default_rng(seed)
     F = frames
     th, tw = height + 4 * F + 64, width + 4 * F + 64
@@ -39,8 +42,13 @@ def make_clip(width, height, frames, seed=7, noise=6):
         py, px = (20 + 3 * t) % max(1, height - 64), (30 + 5 * t) % max(1, width - 64)
         if height >= 64 and width >= 64:
             Y[py:py + 64, px:px + 64] = patch
-        U = ctex_u[y0 // 2:y0 // 2 + height // 2, x0 // 2:x0 // 2 + width // 2]
-        V = ctex_v[y0 // 2:y0 // 2 + height // 2, x0 // 2:x0 // 2 + width // 2]
+        U = ctex_u[y0 // 2:y0 // 2 + height // 2, x0 // 2:x0 // 2 + width // 2].copy()
+        V = ctex_v[y0 // 2:y0 // 2 + height // 2, x0 // 2:x0 // 2 + width // 2].copy()
+        if static_cols:
+            sc = static_cols
+            Y[:, :sc] = tex[:height, :sc]
+            U[:, :sc // 2] = ctex_u[:height // 2, :sc // 2]
+            V[:, :sc // 2] = ctex_v[:height // 2, :sc // 2]
         out.append((np.clip(Y + 0.5, 0, 255).astype(np.uint8),
                     np.clip(U + 0.5, 0, 255).astype(np.uint8),
                     np.clip(V + 0.5, 0, 255).astype(np.uint8)))
