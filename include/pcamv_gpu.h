@@ -160,6 +160,12 @@ int pcamv_gpu_fetch_results(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb, pcamv_embed_t 
  * measured with hipEvents on the launch stream (bench.py roofline). */
 int pcamv_gpu_kernel_time(pcamv_ctx_t *ctx, const char *kernel, double *avg_ms, int *launches, int reset);
 
+/* Pixel-metric probe for parity tests of the cost functions themselves (common/pixel.c SAD/SATD,
+ * common/mc.c get_ref / mc_chroma): n requests {mb_x, mb_y, i_pixel, xoff, yoff, mvx, mvy (qpel),
+ * satd}, each answered with {luma cost, U cost, V cost} of the uploaded fenc block against the
+ * current reference at that MV (no MV-bit cost added). */
+int pcamv_gpu_block_costs(pcamv_ctx_t *ctx, int qp, int n, const int32_t *req, int32_t *out);
+
 int pcamv_gpu_abi_version(void);
 
 #ifdef __cplusplus

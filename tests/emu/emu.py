@@ -1,0 +1,47 @@
+"""TEST-ONLY: build + bind tests/emu/libpcamv_emu.so (the product's control code with scalar prims)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libpcamv_emu.so")
+CSRC = os.path.join(ROOT, "video-steganography-pcamv_amd", "csrc")
+
+
+def build(sanitize=False):
+    srcs = [os.path.join(HERE, "emu_driver.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "pcamv_prims_emu.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):
+        return LIB
+    cmd = ["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+           "-Wno-unused-variable", "-I", CSRC, "-I", HERE, "-o", LIB] + srcs
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def analyse_pframe(orc_mod, params, qp, embed, fenc, ref_planes4, ref_u, ref_v, prev_mv=None, prev_ref=None, diag=1):
+    lib = C.CDLL(build())
+    W, H = params.i_width, params.i_height
+    n_mb = (W // 16) * (H // 16)
+    mbs = np.zeros(n_mb, orc_mod.MB_DTYPE)
+    rec = [np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)]
+    cstride = (W // 2 + 32 + 15) & ~15
+    def padc(a):
+        p = np.pad(a, 16, mode="edge")
+        out = np.zeros((H // 2 + 32, cstride), np.uint8)
+        out[:, :p.shape[1]] = p
+        return out
+    cu, cv = padc(ref_u), padc(ref_v)
+    f = [np.ascontiguousarray(a, np.uint8) for a in fenc]
+    luma = np.ascontiguousarray(ref_planes4, np.uint8)
+    P = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    if prev_mv is not None:
+        prev_mv = np.ascontiguousarray(prev_mv, np.int16); prev_ref = np.ascontiguousarray(prev_ref, np.int8)
+    lib.emu_analyse_pframe(C.byref(params), qp, embed, P(f[0]), P(f[1]), P(f[2]), P(luma), P(cu), P(cv),
+                           P(prev_mv), P(prev_ref), P(mbs), P(rec[0]), P(rec[1]), P(rec[2]), diag)
+    return mbs, rec

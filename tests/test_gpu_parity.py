@@ -1,0 +1,176 @@
+"""Parity tests proper: the HIP path through the C ABI (libpcamv_gpu.so) against (a) the fixtures
+minted from the reference's own C code and (b) the CPU oracle on the same seeded inputs.
+Bit-exact everywhere: MVs, partitions, SAD/SATD scores, RCA costs, reconstruction, planes,
+cover / price / stego / flip vectors.  Run with -m gpu on the MI355X box."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def pc():
+    import pcamv_amd
+    pcamv_amd.load_library()            # fails loudly if the HIP library is missing
+    return pcamv_amd
+
+
+def _params(pc, W, H, me, subme, inter, mv_range, me_range=16, tscale=256):
+    p = pc.param_default(W, H)
+    p.i_me_method, p.i_subpel_refine, p.inter, p.i_mv_range, p.i_me_range, p.i_tscale = me, subme, inter, mv_range, me_range, tscale
+    return p
+
+
+GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
+
+
+@pytest.mark.parametrize("name", GPU_FIXTURES)
+def test_pframe_analysis_matches_reference_fixture(pc, name):
+    g = helpers.load(name)
+    W, H = int(g["width"]), int(g["height"])
+    p = _params(pc, W, H, int(g["me"]), int(g["subme"]), int(g["inter"]), int(g["mv_range"]), int(g["me_range"]))
+    enc = pc.Encoder(p)
+    for t in range(1, int(g["frames"]) + 1):
+        prev = (g[f"f{t}_prev_mv"], g[f"f{t}_prev_ref"]) if f"f{t}_prev_mv" in g else (None, None)
+        enc.set_ref(g[f"f{t}_ref_y"], g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev)
+        enc.upload_fenc(g[f"f{t}_fenc_y"], g[f"f{t}_fenc_u"], g[f"f{t}_fenc_v"])
+        planes = enc.ref_planes()
+        for k in range(4):
+            assert sha(planes[k]) == str(g[f"f{t}_plane_sha"][k]), f"{name} frame {t}: half-pel plane {k}"
+        mbs, rec = enc.analyse_pframe(int(g["qp"]), embed=1)
+        helpers.compare_records(g[f"f{t}_mbs"], mbs, f"{name} frame {t}")
+        for k, nm in enumerate("yuv"):
+            assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
+    enc.close()
+
+
+def test_block_costs_match_oracle(pc):
+    """SAD / SATD / quarter-pel fetch / chroma MC of all 7 block sizes at random MVs."""
+    import ctypes as C
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H = 176, 144
+    clip = make_clip(W, H, 2, seed=21)
+    p = _params(pc, W, H, 1, 5, 0x10, 64)
+    enc = pc.Encoder(p)
+    enc.set_ref(*clip[0]); enc.upload_fenc(*clip[1])
+    o = orc.Oracle(orc.make_params(W, H, mv_range=64))
+    o.set_ref(*clip[0])
+    planes = o.ref_planes(); st = planes.shape[2]
+    cu = np.ascontiguousarray(np.pad(clip[0][1], 16, mode="edge")); cv = np.ascontiguousarray(np.pad(clip[0][2], 16, mode="edge"))
+    rng = np.random.default_rng(3)
+    sizes = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)]
+    offs = {0: [(0, 0)], 1: [(0, 0), (0, 8)], 2: [(0, 0), (8, 0)], 3: [(0, 0), (8, 0), (0, 8), (8, 8)],
+            4: [(0, 4), (8, 12)], 5: [(4, 0), (12, 8)], 6: [(12, 12), (4, 8)]}
+    req = []
+    for i in range(600):
+        ip = i % 7
+        xo, yo = offs[ip][i % len(offs[ip])]
+        req.append([int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16)), ip, xo, yo,
+                    int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), i % 2])
+    got = enc.block_costs(26, req)
+    L = orc.lib()
+    fy, fu, fv = [np.ascontiguousarray(a) for a in clip[1]]
+    for (mbx, mby, ip, xo, yo, mx, my, satd), g3 in zip(req, got):
+        w, h = sizes[ip]
+        fn = L.orc_satd if satd else L.orc_sad
+        src = (C.c_void_p * 4)(*[planes[k].ctypes.data + (32 + mby * 16 + yo) * st + 32 + mbx * 16 + xo for k in range(4)])
+        dst = np.zeros((h, w), np.uint8)
+        L.orc_mc_luma(dst.ctypes.data_as(C.c_void_p), w, src, st, mx, my, w, h)
+        e = C.c_void_p(fy.ctypes.data + (mby * 16 + yo) * W + mbx * 16 + xo)
+        assert fn(ip, e, W, dst.ctypes.data_as(C.c_void_p), w) == g3[0], ("luma", mbx, mby, ip, xo, yo, mx, my, satd)
+        if ip <= 3:
+            for pl, (cpl, fpl) in enumerate(((cu, fu), (cv, fv))):
+                d2 = np.zeros((h // 2, w // 2), np.uint8)
+                L.orc_mc_chroma(d2.ctypes.data_as(C.c_void_p), w // 2,
+                                C.c_void_p(cpl.ctypes.data + (16 + mby * 8 + yo // 2) * cpl.shape[1] + 16 + mbx * 8 + xo // 2),
+                                cpl.shape[1], mx, my, w // 2, h // 2)
+                e2 = C.c_void_p(fpl.ctypes.data + (mby * 8 + yo // 2) * (W // 2) + mbx * 8 + xo // 2)
+                assert fn(ip + 3, e2, W // 2, d2.ctypes.data_as(C.c_void_p), w // 2) == g3[1 + pl], ("chroma", pl, ip, mx, my, satd)
+    enc.close(); o.close()
+
+
+@pytest.mark.parametrize("cfg", [(176, 144, "hex", 5, 0x10, 0.5), (176, 144, "umh", 4, 0x30, 0.5),
+                                 (352, 288, "dia", 3, 0x10, 35.0), (320, 240, "hex", 1, 0x10, 0.25)])
+def test_full_pipeline_matches_oracle_and_extracts(pc, cfg):
+    """analysis + RCA + cover/cost assembly + STC + flips vs the oracle on seeded synthetic frames;
+    then the payload is extracted from the final MVs: BER must be 0."""
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H, me, subme, inter, rate = cfg
+    clip = make_clip(W, H, 3, seed=31, static_cols=64)
+    mvr = pc.level_mv_range(W, H)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr)
+    enc = pc.Encoder(p)
+    o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter))
+    ref, prev = clip[0], (None, None)
+    for t in (1, 2):
+        enc.set_ref(*ref, *prev); enc.upload_fenc(*clip[t])
+        o.set_ref(*ref, *prev); o.set_fenc(*clip[t])
+        assert np.array_equal(enc.ref_planes(), o.ref_planes())
+        mbs, rec = enc.analyse_pframe(28, embed=1)
+        mbs_o, rec_o = o.analyse_pframe(28, 1)
+        for f in mbs.dtype.names:
+            assert np.array_equal(mbs[f], mbs_o[f]), f"frame {t}: {f}"
+        for a, b in zip(rec, rec_o):
+            assert np.array_equal(a, b)
+        emb, emb_o = enc.embed_pframe(rate), o.embed_pframe(mbs_o, rate)
+        assert (emb["n"], emb["m"], emb["stc_ok"], emb["num_flip"]) == (emb_o["n"], emb_o["m"], emb_o["stc_ok"], emb_o["num_flip"])
+        for k in ("cover", "rho", "message", "stego", "flip"):
+            assert np.array_equal(emb[k], emb_o[k]), f"frame {t}: {k}"
+        final = enc.final_mvs(mbs)
+        assert np.array_equal(final["mv"], o.final_mvs(mbs_o, emb_o)["mv"])
+        lsb = helpers.carrier_lsbs(final)
+        assert np.array_equal(lsb, emb["stego"])
+        if emb["stc_ok"] == 1 and emb["m"] >= 10:
+            assert np.array_equal(pc.stc_extract(lsb, emb["m"]), emb["message"]), "BER != 0"
+        prev = helpers.mv_field(final["mv"], W // 16, H // 16)
+        ref = rec
+    enc.close(); o.close()
+
+
+def test_embedding_edge_cases(pc):
+    """user-supplied message, message longer than the cover (stc_embed fails -> all 1-bits flip,
+    encoder.c:1843 ignores the return), and a frame whose every MB is skipped (n = 0)."""
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H = 176, 144
+    clip = make_clip(W, H, 2, seed=4, static_cols=48)
+    p = _params(pc, W, H, 1, 5, 0x10, 64, tscale=0)
+    enc = pc.Encoder(p)
+    o = orc.Oracle(orc.make_params(W, H, mv_range=64, tscale=0))
+    enc.set_ref(*clip[0]); enc.upload_fenc(*clip[1]); o.set_ref(*clip[0]); o.set_fenc(*clip[1])
+    mbs, _ = enc.analyse_pframe(26, 1); mbs_o, _ = o.analyse_pframe(26, 1)
+    msg = np.random.default_rng(0).integers(0, 2, 40).astype(np.uint8)
+    a, b = enc.embed_pframe(40.0, msg), o.embed_pframe(mbs_o, 40.0, msg)
+    for k in ("message", "stego", "flip"):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(a["message"], msg)
+    n = a["n"]
+    a, b = enc.embed_pframe(float(n + 5)), o.embed_pframe(mbs_o, float(n + 5))
+    assert a["stc_ok"] == 0 and b["stc_ok"] == 0 and np.array_equal(a["flip"], a["cover"].astype(np.int8)) and np.array_equal(a["flip"], b["flip"])
+    # identical frames, no noise: every MB becomes P_SKIP, no carriers
+    enc.set_ref(*clip[0]); enc.upload_fenc(*clip[0])
+    mbs, _ = enc.analyse_pframe(30, 1)
+    assert (mbs["i_type"] == pc.P_SKIP).all()
+    e = enc.embed_pframe(0.5)
+    assert e["n"] == 0 and e["m"] == 0 and e["num_flip"] == 0
+    enc.close(); o.close()
+
+
+def test_open_rejects_unsupported(pc):
+    p = pc.param_default(176, 144)
+    p.i_subpel_refine = 7
+    with pytest.raises(pc.PcamvError):
+        pc.Encoder(p)
+    p = pc.param_default(170, 144)
+    with pytest.raises(pc.PcamvError):
+        pc.Encoder(p)

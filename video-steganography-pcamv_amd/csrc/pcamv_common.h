@@ -1,0 +1,113 @@
+/*
+ * pcamv_common.h -- types and tables shared by the HIP kernels and their host launcher.
+ *
+ * Data layout in HBM (one set per context):
+ *   fenc Y/U/V      tightly packed w*h, (w/2)*(h/2) x2
+ *   reference luma  4 planes (full, H, V, HV half-pel) of stride = ALIGN16(w+64), h+64 lines, the
+ *                   picture origin at (32,32): the same values as x264's filtered[0..3] planes
+ *                   (common/frame.c:46-77) after border expansion
+ *   reference chroma 2 planes, stride = ALIGN16(w/2+32), h/2+32 lines, origin (16,16)
+ *   motion field    mv[mb_h*4][mb_w*4][2] int16 qpel, ref8[mb_h*2][mb_w*2], mb_type[n_mb],
+ *                   mvr[n_mb][2] (16x16 search results): h->mb.mv/ref/type/mvr (common.h:433-444)
+ *   record          pcamv_mb_t[n_mb] (include/pcamv_gpu.h) + mvp_aux[n_mb][16][2]
+ */
+#ifndef PCAMV_COMMON_H
+#define PCAMV_COMMON_H
+#include <stdint.h>
+#include "../../include/pcamv_gpu.h"
+
+#ifdef PCAMV_HOST_EMU
+#define PCAMV_DEV static inline
+#define PCAMV_CONST static const
+#else
+#include <hip/hip_runtime.h>
+#define PCAMV_DEV __device__ __forceinline__
+#define PCAMV_CONST __device__ static const
+#endif
+
+#define PCAMV_PAD 32
+#define PCAMV_CPAD 16
+#define PCAMV_COST_MAX (1 << 28)
+#define SCAN8_0 (4 + 1 * 8)
+
+enum { PIX_16x16, PIX_16x8, PIX_8x16, PIX_8x8, PIX_8x4, PIX_4x8, PIX_4x4 };
+
+/* everything a kernel needs to know about one frame; passed by value */
+struct FrameDev {
+    int w, h, mb_w, mb_h, n_mb;
+    int stride, lines, cstride, clines;
+    const uint8_t *fenc[3];
+    uint8_t *luma[4];              /* picture-origin pointers into the padded planes */
+    uint8_t *chroma[2];
+    uint8_t *rec[3];               /* pass-1 reconstruction out, tightly packed */
+    int8_t *mb_type;
+    int16_t *mv;                   /* [n_mb*16][2] */
+    int8_t *ref8;
+    int16_t *mvr;                  /* [n_mb][2] */
+    const int16_t *prev_mv;
+    const int8_t *prev_ref;
+    int have_prev, tscale;
+    pcamv_mb_t *rec_mb;            /* the pass-1 record */
+    int16_t *mvp_aux;              /* [n_mb][16][2] search-time mvp of each carrier slot */
+    const int16_t *cost_mv;        /* centre pointer of the lambda*bits table for this QP */
+    /* parameters */
+    int qp, chroma_qp, lambda;
+    int me_method, me_range, subme, mv_range, b_chroma_me, b_fast_pskip, b_dct_decimate, b_cabac;
+    unsigned inter;
+    int embed;
+    /* quantiser (flat matrices): 3 position classes */
+    int q_mf[2][3], q_bias[2][3], dq_mf[3];    /* [0] luma inter, [1] chroma inter; at qp / chroma_qp */
+    int dq_mf_c[3];
+    int lambda2_chroma;            /* x264_lambda2_tab[chroma_qp] for the skip-probe SSD threshold */
+};
+
+PCAMV_CONST int pix_w_tab[7] = {16, 16, 8, 8, 8, 4, 4};
+PCAMV_CONST int pix_h_tab[7] = {16, 8, 16, 8, 4, 8, 4};
+PCAMV_CONST unsigned char blk_x_tab[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3};
+PCAMV_CONST unsigned char blk_y_tab[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
+PCAMV_CONST int hpel_ref0_tab[16] = {0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1};
+PCAMV_CONST int hpel_ref1_tab[16] = {0, 0, 0, 0, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 3, 2};
+/* zigzag (frame) scan position k -> raster index of the 4x4 coefficient array as dct.c stores it */
+PCAMV_CONST unsigned char zz4_tab[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
+PCAMV_CONST unsigned char decimate_tab4[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+PCAMV_DEV int scan8_of(int idx) { return SCAN8_0 + blk_x_tab[idx] + 8 * blk_y_tab[idx]; }
+PCAMV_DEV int clip3i(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+PCAMV_DEV int iabs(int v) { return v < 0 ? -v : v; }
+PCAMV_DEV int imin(int a, int b) { return a < b ? a : b; }
+PCAMV_DEV int imax(int a, int b) { return a > b ? a : b; }
+PCAMV_DEV int median3i(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }
+
+/* Per-macroblock working set.  On the GPU this lives in LDS (one wavefront = one macroblock);
+ * every lane executes the control code redundantly on wave-uniform values. */
+struct MBLocal {
+    uint8_t fenc[24 * 16];         /* Y 16x16 then U|V 8x8 side by side, stride 16 (x264 fenc_buf layout) */
+    uint8_t recb[24 * 16];         /* reconstruction in the same layout (fenc_buf_ih) */
+    uint8_t pred[24 * 16];         /* prediction -> reconstruction, same layout */
+    int16_t coef[24][16];          /* per 4x4 block coefficients (luma 0..15, U 16..19, V 20..23) */
+    int16_t cdc[2][4];
+    int blk_nz[24], blk_score[24];
+    int16_t cmv[48][2];
+    int8_t cref[48];
+    int16_t pskip_mv[2];
+    int mb_x, mb_y, mb_xy;
+    int mv_min[2], mv_max[2], mv_min_spel[2], mv_max_spel[2], mv_min_fpel[2], mv_max_fpel[2];
+    int neighbour, type_left, type_top, type_topleft, type_topright;
+    int i_type, i_partition;
+    uint8_t sub_part[4];
+    int b_skip_mc, cbp_luma, cbp_chroma;
+    int red[64];                   /* scratch for cross-lane work */
+};
+#define NB_LEFT 1
+#define NB_TOP 2
+#define NB_TOPRIGHT 4
+#define NB_TOPLEFT 8
+
+struct MEState {
+    int i_pixel, xoff, yoff;
+    int mvp[2];
+    int cost_mv, cost, cost_rec;
+    int mv[2];
+};
+
+#endif

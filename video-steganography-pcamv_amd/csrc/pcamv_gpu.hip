@@ -1,0 +1,443 @@
+/*
+ * pcamv_gpu.hip -- host side of libpcamv_gpu.so: the C ABI of include/pcamv_gpu.h over the
+ * gfx950 kernels of pcamv_kernels.hip.h.  There is no CPU path: every entry point needs a HIP
+ * device and fails with PCAMV_ENODEV / PCAMV_EHIP otherwise.
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "pcamv_kernels.hip.h"
+#include "pcamv_host_tables.h"
+
+#define PCAMV_ABI_VERSION 1
+#define NEV 32
+
+struct pcamv_ctx {
+    pcamv_params_t p;
+    int device;
+    hipStream_t stream;
+    FrameDev F;
+    EmbedDev E;
+    int n_diag, slots_per_mb;
+    /* device allocations */
+    uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_chroma[2], *d_rec[3];
+    int8_t *d_mb_type, *d_ref8, *d_prev_ref;
+    int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux;
+    pcamv_mb_t *d_rec_mb;
+    int16_t *d_cost_mv[52];
+    uint8_t *d_cover, *d_stego, *d_message, *d_blk_which, *d_user_msg;
+    float *d_rho; int8_t *d_flip; int *d_hdr, *d_rnd; unsigned *d_cols, *d_path; long long *d_lcg;
+    int cap;
+    /* stc extractor LCG replay */
+    long long lcg_before_last_embed;
+    /* timing of the search phase */
+    hipEvent_t ev0[NEV], ev1[NEV];
+    int ev_n, ev_head;
+    double t_search_ms; int t_search_launches;
+    char err[256];
+};
+
+static int fail(pcamv_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof(c->err), fmt, ap); va_end(ap); }
+    return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, PCAMV_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
+extern "C" const char *pcamv_gpu_last_error(const pcamv_ctx_t *c) { return c ? c->err : "no context"; }
+
+template <class T> static hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+/* glibc srand(seed) state (random_r TYPE_3): the reference draws message bits from rand() with the
+ * default seed 1 (encoder.c:1838-1840) */
+static void glibc_srand_state(int *st, unsigned seed)
+{
+    if (!seed) seed = 1;
+    st[0] = (int)seed;
+    for (int i = 1; i < 31; i++) {
+        long hi = st[i - 1] / 127773, lo = st[i - 1] % 127773, w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        st[i] = (int)w;
+    }
+    int f = 3, b = 0;
+    for (int i = 0; i < 310; i++) {
+        unsigned v = (unsigned)st[f] + (unsigned)st[b];
+        st[f] = (int)v;
+        if (++f >= 31) f = 0;
+        if (++b >= 31) b = 0;
+    }
+    st[31] = f; st[32] = b;
+}
+
+extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t **out)
+{
+    if (!p || !out) return PCAMV_EINVAL;
+    *out = NULL;
+    if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
+    if (p->i_subpel_refine < 1 || p->i_subpel_refine > 5) return PCAMV_EUNSUP;   /* >=6 needs CABAC-size RDO */
+    if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_UMH) return PCAMV_EUNSUP; /* ESA/TESA: next */
+    if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCAMV_ENODEV;
+    pcamv_ctx *c = new (std::nothrow) pcamv_ctx();
+    if (!c) return PCAMV_ENOMEM;
+    memset((void *)c, 0, sizeof(*c));
+    c->p = *p; c->device = device;
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    FrameDev &F = c->F;
+    pcamv_frame_set_params(&F, p);
+    const size_t ysz = (size_t)F.w * F.h, lsz = (size_t)F.stride * F.lines, csz = (size_t)F.cstride * F.clines;
+    for (int i = 0; i < 3; i++) {
+        HIPCHK(c, dalloc(&c->d_fenc[i], i ? ysz / 4 : ysz));
+        HIPCHK(c, dalloc(&c->d_raw[i], i ? ysz / 4 : ysz));
+        HIPCHK(c, dalloc(&c->d_rec[i], i ? ysz / 4 : ysz));
+    }
+    HIPCHK(c, dalloc(&c->d_luma, 4 * lsz + 64));
+    HIPCHK(c, dalloc(&c->d_chroma[0], csz + 64)); HIPCHK(c, dalloc(&c->d_chroma[1], csz + 64));
+    HIPCHK(c, dalloc(&c->d_mb_type, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_ref8, (size_t)F.n_mb * 4)); HIPCHK(c, dalloc(&c->d_prev_ref, (size_t)F.n_mb * 4));
+    HIPCHK(c, dalloc(&c->d_mv, (size_t)F.n_mb * 32)); HIPCHK(c, dalloc(&c->d_prev_mv, (size_t)F.n_mb * 32));
+    HIPCHK(c, dalloc(&c->d_mvr, (size_t)F.n_mb * 2)); HIPCHK(c, dalloc(&c->d_mvp_aux, (size_t)F.n_mb * 32));
+    HIPCHK(c, dalloc(&c->d_rec_mb, (size_t)F.n_mb));
+    HIPCHK(c, hipMemset(c->d_rec_mb, 0, (size_t)F.n_mb * sizeof(pcamv_mb_t)));
+    HIPCHK(c, hipMemset(c->d_mv, 0, (size_t)F.n_mb * 64)); HIPCHK(c, hipMemset(c->d_mvr, 0, (size_t)F.n_mb * 4));
+    HIPCHK(c, hipMemset(c->d_mvp_aux, 0, (size_t)F.n_mb * 64));
+    c->cap = 16 * F.n_mb;
+    HIPCHK(c, dalloc(&c->d_cover, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_stego, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_message, (size_t)c->cap));
+    HIPCHK(c, dalloc(&c->d_blk_which, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_user_msg, (size_t)c->cap));
+    HIPCHK(c, dalloc(&c->d_rho, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_flip, (size_t)c->cap));
+    HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 72)); HIPCHK(c, dalloc(&c->d_lcg, 1));
+    HIPCHK(c, dalloc(&c->d_path, (size_t)c->cap * 32));
+    HIPCHK(c, hipMemset(c->d_hdr, 0, 8 * sizeof(int)));
+    int rnd[40]; memset(rnd, 0, sizeof(rnd)); glibc_srand_state(rnd, 1);
+    HIPCHK(c, hipMemcpy(c->d_rnd, rnd, sizeof(rnd), hipMemcpyHostToDevice));
+    long long lcg = 1; HIPCHK(c, hipMemcpy(c->d_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
+    c->lcg_before_last_embed = 1;
+    for (int i = 0; i < 3; i++) { F.fenc[i] = c->d_fenc[i]; F.rec[i] = c->d_rec[i]; }
+    for (int k = 0; k < 4; k++) F.luma[k] = c->d_luma + k * lsz + (size_t)F.stride * PCAMV_PAD + PCAMV_PAD;
+    for (int k = 0; k < 2; k++) F.chroma[k] = c->d_chroma[k] + (size_t)F.cstride * PCAMV_CPAD + PCAMV_CPAD;
+    F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
+    F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
+    F.rec_mb = c->d_rec_mb; F.mvp_aux = c->d_mvp_aux;
+    c->n_diag = F.mb_w + 2 * (F.mb_h - 1);
+    c->slots_per_mb = (p->inter & PCAMV_ANALYSE_PSUB8x8) ? 16 : 2;
+    EmbedDev &E = c->E;
+    E.mbs = c->d_rec_mb; E.n_mb = F.n_mb; E.cover = c->d_cover; E.stego = c->d_stego; E.message = c->d_message; E.rho = c->d_rho;
+    E.flip = c->d_flip; E.hdr = c->d_hdr; E.blk_which = c->d_blk_which; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
+    E.lcg = c->d_lcg; E.cap = c->cap; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
+    for (int i = 0; i < NEV; i++) { HIPCHK(c, hipEventCreate(&c->ev0[i])); HIPCHK(c, hipEventCreate(&c->ev1[i])); }
+    *out = c;
+    return 0;
+}
+
+extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
+    hipFree(c->d_luma); hipFree(c->d_chroma[0]); hipFree(c->d_chroma[1]);
+    hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
+    hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb);
+    for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);
+    hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_blk_which); hipFree(c->d_user_msg); hipFree(c->d_rho);
+    hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
+    for (int i = 0; i < NEV; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int ensure_qp(pcamv_ctx *c, int qp)
+{
+    if (qp < 0 || qp > 51) return fail(c, PCAMV_EINVAL, "qp %d out of range", qp);
+    if (!c->d_cost_mv[qp]) {
+        int16_t *h = (int16_t *)malloc(PCAMV_COST_MV_LEN * sizeof(int16_t));
+        if (!h) return fail(c, PCAMV_ENOMEM, "cost table");
+        pcamv_build_cost_mv(qp, h);
+        hipError_t e = dalloc(&c->d_cost_mv[qp], (size_t)PCAMV_COST_MV_LEN);
+        if (e == hipSuccess) e = hipMemcpy(c->d_cost_mv[qp], h, PCAMV_COST_MV_LEN * sizeof(int16_t), hipMemcpyHostToDevice);
+        free(h);
+        if (e != hipSuccess) return fail(c, PCAMV_EHIP, "cost table upload: %s", hipGetErrorString(e));
+    }
+    pcamv_frame_set_qp(&c->F, &c->p, qp);
+    c->F.cost_mv = c->d_cost_mv[qp] + PCAMV_COST_MV_CENTRE;
+    return 0;
+}
+
+extern "C" int pcamv_gpu_upload_fenc(pcamv_ctx_t *c, const uint8_t *const plane[3], const int stride[3])
+{
+    if (!c || !plane || !stride) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 3; i++) {
+        int w = c->F.w >> !!i, h = c->F.h >> !!i;
+        HIPCHK(c, hipMemcpy2DAsync(c->d_fenc[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int pcamv_gpu_set_fenc_device(pcamv_ctx_t *c, const void *y, const void *u, const void *v)
+{
+    if (!c || !y || !u || !v) return PCAMV_EINVAL;
+    c->F.fenc[0] = (const uint8_t *)y; c->F.fenc[1] = (const uint8_t *)u; c->F.fenc[2] = (const uint8_t *)v;
+    return 0;
+}
+
+/* plane production on the stream: raw Y/U/V (device) -> padded full/H/V/HV + padded chroma */
+static int launch_plane_production(pcamv_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v, hipStream_t st)
+{
+    const FrameDev &F = c->F;
+    dim3 g((F.stride + HT_W - 1) / HT_W, (F.lines + HT_H - 1) / HT_H);
+    hipLaunchKernelGGL(k_hpel, g, dim3(256), 0, st, y, c->d_luma, F.w, F.h, F.stride, F.lines);
+    dim3 gc((F.cstride + 255) / 256, F.clines);
+    hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, u, c->d_chroma[0], F.w / 2, F.h / 2, F.cstride, F.clines);
+    hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, v, c->d_chroma[1], F.w / 2, F.h / 2, F.cstride, F.clines);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "plane production launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pcamv_gpu_set_ref(pcamv_ctx_t *c, const uint8_t *const plane[3], const int stride[3], const int16_t *prev_mv, const int8_t *prev_ref)
+{
+    if (!c || !plane || !stride) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 3; i++) {
+        int w = c->F.w >> !!i, h = c->F.h >> !!i;
+        HIPCHK(c, hipMemcpy2DAsync(c->d_raw[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice, c->stream));
+    }
+    c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
+    c->F.prev_mv = c->d_prev_mv; c->F.prev_ref = c->d_prev_ref;
+    if (c->F.have_prev) {
+        HIPCHK(c, hipMemcpyAsync(c->d_prev_mv, prev_mv, (size_t)c->F.n_mb * 64, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_prev_ref, prev_ref, (size_t)c->F.n_mb * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = launch_plane_production(c, c->d_raw[0], c->d_raw[1], c->d_raw[2], c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int pcamv_gpu_set_ref_device(pcamv_ctx_t *c, const void *y, const void *u, const void *v, const void *prev_mv, const void *prev_ref)
+{
+    if (!c || !y || !u || !v) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
+    if (c->F.have_prev) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; }
+    /* the filter itself runs as the first kernels of the next step (plane production is part of the timed path) */
+    c->d_raw[0] = c->d_raw[0];
+    HIPCHK(c, hipMemcpyAsync(c->d_raw[0], y, (size_t)c->F.w * c->F.h, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw[1], u, (size_t)c->F.w * c->F.h / 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw[2], v, (size_t)c->F.w * c->F.h / 4, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int pcamv_gpu_get_ref_planes(pcamv_ctx_t *c, uint8_t *out, int *stride, int *lines)
+{
+    if (!c || !out) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_luma, 4 * (size_t)c->F.stride * c->F.lines, hipMemcpyDeviceToHost));
+    if (stride) *stride = c->F.stride;
+    if (lines) *lines = c->F.lines;
+    return 0;
+}
+
+static int launch_analysis(pcamv_ctx *c, int embed, hipStream_t st, int timed)
+{
+    c->F.embed = embed;
+    const FrameDev F = c->F;
+    int slot = -1;
+    if (timed) { slot = c->ev_head; hipEventRecord(c->ev0[slot], st); }
+    for (int d = 0; d < c->n_diag; d++) {
+        int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+        int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+        int cnt = y_hi - y_lo + 1;
+        if (cnt <= 0) continue;
+        hipLaunchKernelGGL(k_search_diag, dim3(cnt), dim3(64), 0, st, F, d);
+    }
+    if (timed) { hipEventRecord(c->ev1[slot], st); c->ev_head = (c->ev_head + 1) % NEV; if (c->ev_n < NEV) c->ev_n++; }
+    if (embed) hipLaunchKernelGGL(k_rca, dim3(F.n_mb * c->slots_per_mb), dim3(64), 0, st, F, c->slots_per_mb);
+    hipLaunchKernelGGL(k_encode, dim3(F.n_mb), dim3(64), 0, st, F);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "analysis launch: %s", hipGetErrorString(e));
+    return 0;
+}
+static int launch_embed(pcamv_ctx *c, float emrate, hipStream_t st)
+{
+    c->E.emrate = emrate;
+    hipLaunchKernelGGL(k_embed_prepare, dim3(1), dim3(1024), 0, st, c->E);
+    hipLaunchKernelGGL(k_stc_forward, dim3(1), dim3(1024), 0, st, c->E);
+    hipLaunchKernelGGL(k_stc_backward, dim3(1), dim3(64), 0, st, c->E);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "embed launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pcamv_gpu_analyse_pframe(pcamv_ctx_t *c, int qp, int embed, pcamv_mb_t *out_mb, uint8_t *const recon[3])
+{
+    if (!c || !out_mb) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_qp(c, qp);
+    if (rc) return rc;
+    if ((rc = launch_analysis(c, embed, c->stream, 1))) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost, c->stream));
+    if (recon)
+        for (int i = 0; i < 3; i++)
+            if (recon[i]) HIPCHK(c, hipMemcpyAsync(recon[i], c->d_rec[i], ((size_t)c->F.w * c->F.h) >> (i ? 2 : 0), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int fetch_embed(pcamv_ctx *c, pcamv_embed_t *out)
+{
+    int hdr[8];
+    HIPCHK(c, hipMemcpyAsync(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->n = hdr[0]; out->m = hdr[1]; out->stc_ok = hdr[2]; out->num_flip = hdr[3];
+    if (out->n > c->cap || out->m > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
+    if (out->cover) HIPCHK(c, hipMemcpy(out->cover, c->d_cover, out->n, hipMemcpyDeviceToHost));
+    if (out->rho) HIPCHK(c, hipMemcpy(out->rho, c->d_rho, (size_t)out->n * 4, hipMemcpyDeviceToHost));
+    if (out->stego) HIPCHK(c, hipMemcpy(out->stego, c->d_stego, out->n, hipMemcpyDeviceToHost));
+    if (out->flip) HIPCHK(c, hipMemcpy(out->flip, c->d_flip, out->n, hipMemcpyDeviceToHost));
+    if (out->message) HIPCHK(c, hipMemcpy(out->message, c->d_message, out->m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pcamv_gpu_embed_pframe(pcamv_ctx_t *c, float emrate, const uint8_t *message, int message_len, pcamv_embed_t *out)
+{
+    if (!c || !out || emrate <= 0) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(&c->lcg_before_last_embed, c->d_lcg, sizeof(long long), hipMemcpyDeviceToHost));
+    if (message) {
+        if (message_len < 0 || message_len > c->cap) return fail(c, PCAMV_EINVAL, "message_len");
+        HIPCHK(c, hipMemcpyAsync(c->d_user_msg, message, message_len, hipMemcpyHostToDevice, c->stream));
+        c->E.user_message = c->d_user_msg; c->E.user_message_len = message_len;
+    } else { c->E.user_message = NULL; c->E.user_message_len = 0; }
+    int rc = launch_embed(c, emrate, c->stream);
+    if (rc) return rc;
+    return fetch_embed(c, out);
+}
+
+extern "C" int pcamv_gpu_step_device(pcamv_ctx_t *c, int qp, float emrate, void *stream)
+{
+    if (!c) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    int rc = ensure_qp(c, qp);
+    if (rc) return rc;
+    if ((rc = launch_plane_production(c, c->d_raw[0], c->d_raw[1], c->d_raw[2], st))) return rc;
+    if ((rc = launch_analysis(c, emrate > 0, st, 1))) return rc;
+    if (emrate > 0) { c->E.user_message = NULL; c->E.user_message_len = 0; if ((rc = launch_embed(c, emrate, st))) return rc; }
+    return 0;
+}
+extern "C" int pcamv_gpu_fetch_results(pcamv_ctx_t *c, pcamv_mb_t *out_mb, pcamv_embed_t *out)
+{
+    if (!c) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (out_mb) HIPCHK(c, hipMemcpy(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
+    if (out) return fetch_embed(c, out);
+    return 0;
+}
+
+extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double *avg_ms, int *launches, int reset)
+{
+    if (!c || !kernel || strcmp(kernel, "k_search_diag")) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    for (int i = 0; i < c->ev_n; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess) { c->t_search_ms += ms; c->t_search_launches += c->n_diag; }
+    }
+    c->ev_n = 0; c->ev_head = 0;
+    if (avg_ms) *avg_ms = c->t_search_launches ? c->t_search_ms / c->t_search_launches : 0;
+    if (launches) *launches = c->t_search_launches;
+    if (reset) { c->t_search_ms = 0; c->t_search_launches = 0; }
+    return 0;
+}
+
+extern "C" int pcamv_gpu_block_costs(pcamv_ctx_t *c, int qp, int n, const int32_t *req, int32_t *out)
+{
+    if (!c || !req || !out || n <= 0) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) {
+        const int32_t *r = req + 8 * i;
+        if (r[0] < 0 || r[0] >= c->F.mb_w || r[1] < 0 || r[1] >= c->F.mb_h || r[2] < 0 || r[2] > 6) return fail(c, PCAMV_EINVAL, "request %d", i);
+        int px = r[0] * 16 + r[3] + (r[5] >> 2), py = r[1] * 16 + r[4] + (r[6] >> 2);    /* stay inside the 32-pixel padding */
+        if (px < -28 || py < -28 || px + 20 > c->F.w + 28 || py + 20 > c->F.h + 28) return fail(c, PCAMV_EINVAL, "request %d leaves the padded plane", i);
+    }
+    int rc = ensure_qp(c, qp);
+    if (rc) return rc;
+    int *d_req = NULL, *d_out = NULL;
+    HIPCHK(c, dalloc(&d_req, (size_t)n * 8)); HIPCHK(c, dalloc(&d_out, (size_t)n * 3));
+    HIPCHK(c, hipMemcpy(d_req, req, (size_t)n * 8 * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_block_costs, dim3(n), dim3(64), 0, c->stream, c->F, d_req, d_out);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(d_req); hipFree(d_out);
+    return 0;
+}
+
+/* pass-2 substitution (analyse.c:3001-3107) on a fetched record: host-side, trivial */
+extern "C" int pcamv_gpu_final_mvs(pcamv_ctx_t *c, pcamv_mb_t *mbs)
+{
+    if (!c || !mbs) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int hdr[8];
+    HIPCHK(c, hipMemcpy(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
+    int n = hdr[0];
+    if (n < 0 || n > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
+    int8_t *flip = (int8_t *)malloc(n ? n : 1);
+    if (!flip) return fail(c, PCAMV_ENOMEM, "flip");
+    hipError_t e = hipMemcpy(flip, c->d_flip, n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(flip); return fail(c, PCAMV_EHIP, "flip download"); }
+    int k = 0;
+    for (int xy = 0; xy < c->F.n_mb; xy++) {
+        int slots[16], cs = 0;
+        const pcamv_mb_t *mb = &mbs[xy];
+        if (mb->used) {
+            if (mb->i_type == PCAMV_P_8x8) {
+                for (int i = 0; i < 4; i++)
+                    switch (mb->i_sub_partition[i]) {
+                    case PCAMV_D_L0_8x8: slots[cs++] = i * 4; break;
+                    case PCAMV_D_L0_4x8: slots[cs++] = i * 4; slots[cs++] = i * 4 + 1; break;
+                    case PCAMV_D_L0_8x4: slots[cs++] = i * 4; slots[cs++] = i * 4 + 2; break;
+                    default: for (int j = 0; j < 4; j++) slots[cs++] = i * 4 + j; break;
+                    }
+            } else if (mb->i_type == PCAMV_P_L0) {
+                slots[cs++] = 0;
+                if (mb->i_partition == PCAMV_D_8x16) slots[cs++] = 4;
+                else if (mb->i_partition == PCAMV_D_16x8) slots[cs++] = 8;
+            }
+        }
+        for (int i = 0; i < cs && k < n; i++, k++)
+            if (flip[k] == 1) { mbs[xy].mv[slots[i]][0] = mbs[xy].mv_stego[slots[i]][0]; mbs[xy].mv[slots[i]][1] = mbs[xy].mv_stego[slots[i]][1]; }
+    }
+    free(flip);
+    return 0;
+}
+
+/* syndrome-trellis extractor: H*y over GF(2) with stc_embed's sub-matrix schedule (embed.h:340-393) */
+extern "C" int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int hgt, uint8_t *message)
+{
+    if (!stego || !message || n <= 0 || m <= 0 || m > n || hgt < 7 || hgt > 12) return PCAMV_EINVAL;
+    double invalpha = (double)n / m;
+    int shorter = (int)floor(invalpha), longer = (int)ceil(invalpha);
+    if (shorter < 2 || longer > 20) return PCAMV_EUNSUP;   /* LCG-generated columns depend on process history */
+    const unsigned *cs = &pcamv_stc_mats[(hgt - 7) * 400 + (shorter - 1) * 20], *cl = &pcamv_stc_mats[(hgt - 7) * 400 + (longer - 1) * 20];
+    memset(message, 0, m);
+    int worm = 0, index = 0;
+    for (int i = 0; i < m; i++) {
+        int lng = worm + longer <= (i + 1) * invalpha + 0.5;
+        int width = lng ? longer : shorter;
+        const unsigned *cols = lng ? cl : cs;
+        worm += width;
+        for (int k = 0; k < width && index < n; k++, index++)
+            if (stego[index])
+                for (int b = 0; b < hgt && i + b < m; b++) message[i + b] ^= (cols[k] >> b) & 1;
+    }
+    return 0;
+}

@@ -1,0 +1,366 @@
+/*
+ * pcamv_kernels.hip.h -- the __global__ kernels (gfx950).
+ *
+ *   k_chroma_pad      reference chroma -> padded planes (x264_frame_expand_border, frame.c:246)
+ *   k_hpel            reference luma -> 4 padded planes full/H/V/HV, LDS-tiled 6-tap filter
+ *                     (hpel_filter mc.c:167-190 + both border expansions, frame.c:246-301, in
+ *                     closed form: value(x,y) = filter(clamp(x,-4,W+3), clamp(y,-8,H+7)))
+ *   k_search_diag     phase A for one anti-diagonal, one wavefront per macroblock
+ *   k_rca             phase B, one wavefront per (macroblock, carrier slot)
+ *   k_encode          phase C, one wavefront per macroblock
+ *   k_embed_prepare   cover / cost assembly + MVC adjustment + message (encoder.c:1561-1840)
+ *   k_stc_forward/backward  syndrome-trellis Viterbi (embed.h:309-548), 1024 states = 1024 lanes
+ */
+#ifndef PCAMV_KERNELS_HIP_H
+#define PCAMV_KERNELS_HIP_H
+#include "pcamv_common.h"
+#include "pcamv_prims_gpu.h"
+#include "pcamv_mbkernels.h"
+#include "stc_mats.h"
+
+/* ------------------------------------------------------------------ plane production */
+__global__ void __launch_bounds__(256) k_chroma_pad(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, int cstride, int clines)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cstride || y >= clines) return;
+    int sx = clip3i(x - PCAMV_CPAD, 0, w - 1), sy = clip3i(y - PCAMV_CPAD, 0, h - 1);
+    dst[(size_t)y * cstride + x] = src[(size_t)sy * w + sx];
+}
+
+#define HT_W 64
+#define HT_H 16
+__global__ void __launch_bounds__(256) k_hpel(const uint8_t *__restrict__ src, uint8_t *__restrict__ planes, int W, int H, int stride, int lines)
+{
+    __shared__ uint8_t s_src[HT_H + 5][HT_W + 8];
+    __shared__ int16_t s_v[HT_H][HT_W + 8];
+    const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H;          /* padded-plane coordinates */
+    const int tid = threadIdx.x;
+    /* effective picture coordinates of this tile (clamp is monotonic, so the range is contiguous) */
+    const int ex0 = clip3i(x0 - PCAMV_PAD, -4, W + 3), ey0 = clip3i(y0 - PCAMV_PAD, -8, H + 7);
+    /* stage A: source tile, columns ex0-2 .. ex0+HT_W+2, rows ey0-2 .. ey0+HT_H+2, clamped into the picture */
+    for (int i = tid; i < (HT_H + 5) * (HT_W + 5); i += 256) {
+        int r = i / (HT_W + 5), c = i - r * (HT_W + 5);
+        int sx = clip3i(ex0 - 2 + c, 0, W - 1), sy = clip3i(ey0 - 2 + r, 0, H - 1);
+        s_src[r][c] = src[(size_t)sy * W + sx];
+    }
+    __syncthreads();
+    /* stage B: unrounded vertical 6-tap for every column of the tile */
+    for (int i = tid; i < HT_H * (HT_W + 5); i += 256) {
+        int r = i / (HT_W + 5), c = i - r * (HT_W + 5);
+        int t = s_src[r][c] + s_src[r + 5][c] - 5 * (s_src[r + 1][c] + s_src[r + 4][c]) + 20 * (s_src[r + 2][c] + s_src[r + 3][c]);
+        s_v[r][c] = (int16_t)t;
+    }
+    __syncthreads();
+    /* stage C: 4 horizontally adjacent outputs per thread and plane */
+    const size_t psz = (size_t)stride * lines;
+    const int ty = tid >> 4, tx = (tid & 15) * 4;
+    const int y = y0 + ty;
+    if (y < lines) {
+        const int ey = clip3i(y - PCAMV_PAD, -8, H + 7), r = ey - ey0;
+        uint32_t of = 0, oh = 0, ov = 0, oc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int x = x0 + tx + k;
+            int px = clip3i(x - PCAMV_PAD, 0, W - 1), py = clip3i(y - PCAMV_PAD, 0, H - 1);
+            int ex = clip3i(x - PCAMV_PAD, -4, W + 3), c = ex - ex0 + 2;       /* column in the tiles */
+            /* integer plane: plain replicate padding; taken from the tile when inside it, else from memory */
+            int f = src[(size_t)py * W + px];
+            const uint8_t *sr = &s_src[r + 2][c];
+            int th = sr[-2] + sr[3] - 5 * (sr[-1] + sr[2]) + 20 * (sr[0] + sr[1]);
+            const int16_t *vr = &s_v[r][c];
+            int tc = vr[-2] + vr[3] - 5 * (vr[-1] + vr[2]) + 20 * (vr[0] + vr[1]);
+            of |= (uint32_t)f << (8 * k);
+            oh |= (uint32_t)clip3i((th + 16) >> 5, 0, 255) << (8 * k);
+            ov |= (uint32_t)clip3i((vr[0] + 16) >> 5, 0, 255) << (8 * k);
+            oc |= (uint32_t)clip3i((tc + 512) >> 10, 0, 255) << (8 * k);
+        }
+        if (x0 + tx < stride) {
+            size_t o = (size_t)y * stride + x0 + tx;
+            *(uint32_t *)(planes + o) = of;
+            *(uint32_t *)(planes + psz + o) = oh;
+            *(uint32_t *)(planes + 2 * psz + o) = ov;
+            *(uint32_t *)(planes + 3 * psz + o) = oc;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ analysis phases */
+__global__ void __launch_bounds__(64) k_search_diag(FrameDev F, int d)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    /* MBs of the anti-diagonal x + 2y = d */
+    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    int y = y_lo + (int)blockIdx.x, x = d - 2 * y;
+    if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
+    mbk_search(F, &L, &A, x, y);
+}
+__global__ void __launch_bounds__(64) k_rca(FrameDev F, int slots_per_mb)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    int xy = blockIdx.x / slots_per_mb, k = blockIdx.x - xy * slots_per_mb;
+    if (xy >= F.n_mb) return;
+    mbk_rca(F, &L, &A, xy, k);
+}
+__global__ void __launch_bounds__(64) k_encode(FrameDev F)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    if ((int)blockIdx.x >= F.n_mb) return;
+    mbk_encode(F, &L, &A, blockIdx.x);
+}
+
+/* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
+ * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */
+__global__ void __launch_bounds__(64) k_block_costs(FrameDev F, const int *__restrict__ req, int *__restrict__ out)
+{
+    __shared__ MBLocal L;
+    const int *r = req + 8 * blockIdx.x;
+    L.mb_x = r[0]; L.mb_y = r[1]; L.mb_xy = r[1] * F.mb_w + r[0];
+    prim_load_fenc(F, &L);
+    int luma = prim_cost_luma(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7]);
+    int cu = 0, cv = 0;
+    if (r[2] <= PIX_8x8) prim_cost_chroma_uv(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7], &cu, &cv);
+    if (LANE() == 0) { out[3 * blockIdx.x] = luma; out[3 * blockIdx.x + 1] = cu; out[3 * blockIdx.x + 2] = cv; }
+}
+
+/* ------------------------------------------------------------------ embedding stage */
+struct EmbedDev {
+    const pcamv_mb_t *mbs; int n_mb;
+    uint8_t *cover, *stego, *message; float *rho; int8_t *flip;
+    int *hdr;                 /* [0]=n [1]=m [2]=stc_ok [3]=num_flip [4]=sum(width) */
+    uint8_t *blk_which;       /* per message bit: 0 = shorter, 1 = longer sub-matrix */
+    unsigned *cols;           /* [2][32] columns of the two sub-matrices; cols[64]=shorter, cols[65]=longer */
+    unsigned *path;           /* n * 32 words */
+    int *rnd;                 /* glibc rand state: r[0..30], f, b */
+    long long *lcg;           /* STC column LCG state (embed.h:134) */
+    float emrate;
+    const uint8_t *user_message; int user_message_len;
+    int cap;                  /* capacity of the per-carrier arrays */
+};
+
+__device__ __forceinline__ int dev_is01(int d) { return d == 0 || d == 1; }
+
+__device__ int dev_glibc_rand(int *st)
+{
+    int f = st[31], b = st[32];
+    unsigned v = (unsigned)st[f] + (unsigned)st[b];
+    st[f] = (int)v;
+    if (++f >= 31) f = 0;
+    if (++b >= 31) b = 0;
+    st[31] = f; st[32] = b;
+    return (int)((v >> 1) & 0x7fffffff);
+}
+__device__ int dev_stc_matrix(int width, int height, unsigned *cols, long long *lcg)
+{
+    if (width >= 2 && width <= 20 && height >= 7 && height <= 12) {
+        for (int i = 0; i < width; i++) cols[i] = pcamv_stc_mats_dev[(height - 7) * 400 + (width - 1) * 20 + i];
+        return 1;
+    }
+    if (width > 32 || (1 << (height - 2)) < width) return 0;
+    unsigned mask = (1u << (height - 2)) - 1, bop = (1u << (height - 1)) + 1;
+    long hold = (long)*lcg;
+    for (int i = 0; i < width; i++) {
+        unsigned r; int j;
+        for (j = -1; j < i;) {
+            hold = hold * 214013L + 2531011L;
+            r = (((unsigned)(hold >> 16) & 0x7fff & mask) << 1) + bop;
+            for (j = 0; j < i; j++) if (cols[j] == r) break;
+        }
+        cols[i] = r;
+    }
+    *lcg = hold;
+    return 1;
+}
+
+__global__ void __launch_bounds__(1024) k_embed_prepare(EmbedDev E)
+{
+    __shared__ int s_cnt[1024];
+    const int t = threadIdx.x;
+    const int chunk = (E.n_mb + 1023) / 1024;
+    const int lo = t * chunk, hi = min(E.n_mb, lo + chunk);
+    int cnt = 0, slots[16];
+    for (int xy = lo; xy < hi; xy++) {
+        const pcamv_mb_t *mb = &E.mbs[xy];
+        cnt += carrier_slots(mb->i_type, mb->i_partition, mb->i_sub_partition, mb->used, slots);
+    }
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          /* inclusive Hillis-Steele scan */
+        int v = t >= off ? s_cnt[t - off] : 0;
+        __syncthreads();
+        s_cnt[t] += v;
+        __syncthreads();
+    }
+    int base = s_cnt[t] - cnt;
+    const int n = s_cnt[1023];
+    const float mvc_c1 = 2, mvc_c2 = 0.7f;
+    for (int xy = lo; xy < hi; xy++) {
+        const pcamv_mb_t *mb = &E.mbs[xy];
+        int k = carrier_slots(mb->i_type, mb->i_partition, mb->i_sub_partition, mb->used, slots);
+        if (!k) continue;
+        float rho[16];
+        for (int i = 0; i < k; i++) {
+            E.cover[base + i] = (uint8_t)((mb->mv[slots[i]][0] + mb->mv[slots[i]][1]) & 1);
+            rho[i] = (float)mb->inter_stego_cost[slots[i]];
+        }
+#define MVD(a, b, c) iabs(mb->mv[a][c] - mb->mv[b][c])
+        if (mb->i_type == PCAMV_P_8x8) {
+            const uint8_t *sp = mb->i_sub_partition;
+            int len = 0;
+            if (sp[0] == PCAMV_D_L0_8x8 && sp[1] == PCAMV_D_L0_8x8 && sp[2] == PCAMV_D_L0_8x8 && sp[3] == PCAMV_D_L0_8x8) {
+                int c = dev_is01(MVD(0, 4, 0)) + dev_is01(MVD(4, 12, 0)) + dev_is01(MVD(12, 8, 0)) + dev_is01(MVD(8, 0, 0)) +
+                        dev_is01(MVD(0, 4, 1)) + dev_is01(MVD(4, 12, 1)) + dev_is01(MVD(12, 8, 1)) + dev_is01(MVD(8, 0, 1));
+                float fac = __fadd_rn(__fmul_rn(mvc_c2, (float)c), 1.0f);
+                for (int j = 0; j < 4; j++) rho[j] = __fmul_rn(rho[j], fac);
+            }
+            for (int i = 0; i < 4; i++) {
+                if (sp[i] == PCAMV_D_L0_8x8) len += 1;
+                else if (sp[i] == PCAMV_D_L0_4x8 || sp[i] == PCAMV_D_L0_8x4) {
+                    int b = sp[i] == PCAMV_D_L0_4x8 ? 4 * i + 1 : 4 * i + 2;
+                    if (MVD(4 * i, b, 0) + MVD(4 * i, b, 1) < 2) { rho[len] = __fmul_rn(rho[len], mvc_c1); rho[len + 1] = __fmul_rn(rho[len + 1], mvc_c1); }
+                    len += 2;
+                } else {
+                    int q = 4 * i;
+                    int c = dev_is01(MVD(q, q + 1, 0)) + dev_is01(MVD(q + 1, q + 3, 0)) + dev_is01(MVD(q + 2, q + 3, 0)) + dev_is01(MVD(q, q + 2, 0)) +
+                            dev_is01(MVD(q, q + 1, 1)) + dev_is01(MVD(q + 1, q + 3, 1)) + dev_is01(MVD(q + 2, q + 3, 1)) + dev_is01(MVD(q, q + 2, 1));
+                    float fac = __fadd_rn(__fmul_rn(mvc_c2, (float)c), 1.0f);
+                    for (int j = 0; j < 4; j++) rho[len + j] = __fmul_rn(rho[len + j], fac);
+                    len += 4;
+                }
+            }
+        } else if (mb->i_partition != PCAMV_D_16x16) {
+            int b = mb->i_partition == PCAMV_D_8x16 ? 4 : 8;
+            if (MVD(0, b, 0) + MVD(0, b, 1) < 2) { rho[0] = __fmul_rn(rho[0], mvc_c1); rho[1] = __fmul_rn(rho[1], mvc_c1); }
+        }
+#undef MVD
+        for (int i = 0; i < k; i++) E.rho[base + i] = rho[i];
+        base += k;
+    }
+    for (int i = t; i < E.cap; i += 1024) { E.stego[i] = 0; E.flip[i] = 0; }
+    if (t == 0) {
+        int m = E.emrate > 1.0f ? (int)E.emrate : (int)__fmul_rn(E.emrate, (float)n);
+        if (m < 0) m = 0;
+        E.hdr[0] = n; E.hdr[1] = m; E.hdr[2] = 0; E.hdr[3] = 0; E.hdr[4] = 0;
+        for (int i = 0; i < m; i++)
+            E.message[i] = E.user_message ? (i < E.user_message_len ? E.user_message[i] : 0) : (uint8_t)(dev_glibc_rand(E.rnd) & 1);
+        /* sub-matrix schedule, embed.h:340-393 */
+        if (m > 0 && m <= n) {
+            double invalpha = (double)n / m;
+            int shorter = (int)floor(invalpha), longer = (int)ceil(invalpha);
+            if (dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + 32, E.lcg)) {
+                E.cols[64] = shorter; E.cols[65] = longer;
+                int worm = 0;
+                for (int i = 0; i < m; i++) {
+                    if (worm + longer <= (i + 1) * invalpha + 0.5) { E.blk_which[i] = 1; worm += longer; }
+                    else { E.blk_which[i] = 0; worm += shorter; }
+                }
+                E.hdr[4] = worm;
+                E.hdr[2] = -1;          /* schedule valid, Viterbi pending */
+            }
+        }
+    }
+}
+
+/* forward Viterbi: thread = trellis state.  new[s] = min(p[s] + c_stay, p[s^col] + c_flip), path bit
+ * set when the flip branch is <= (embed.h:439-467 evaluated per state; ties and infinities behave
+ * identically because both formulations add and compare the same two floats). */
+__global__ void __launch_bounds__(1024) k_stc_forward(EmbedDev E)
+{
+    __shared__ float s_p[2][1024];
+    __shared__ float s_rho[256];
+    __shared__ uint8_t s_cov[256];
+    const int s = threadIdx.x, lane = s & 63, wv = s >> 6;
+    if (E.hdr[2] != -1) return;
+    const int n = E.hdr[0], m = E.hdr[1], nproc = E.hdr[4];
+    const int hgt = 10;
+    const unsigned wshort = E.cols[64], wlong = E.cols[65];
+    float inf = __int_as_float(0x7F800000);
+    int cur = 0;
+    s_p[0][s] = s == 0 ? 0.0f : inf;
+    unsigned colmask = 1023;
+    double total = 0;
+    int index = 0;
+    for (int i2 = 0; i2 < m; i2++) {
+        const int which = E.blk_which[i2];
+        const int width = which ? wlong : wshort;
+        for (int k = 0; k < width; k++, index++) {
+            if ((index & 255) == 0) {
+                __syncthreads();
+                if (s < 256 && index + s < nproc) { s_rho[s] = E.rho[index + s]; s_cov[s] = E.cover[index + s]; }
+                __syncthreads();
+            }
+            const unsigned column = E.cols[which * 32 + k] & colmask;
+            const float r = s_rho[index & 255];
+            const float c1 = s_cov[index & 255] == 0 ? 0.0f : r, c2 = s_cov[index & 255] == 0 ? r : 0.0f;
+            total += r;
+            const float stay = __fadd_rn(s_p[cur][s], c1), flp = __fadd_rn(s_p[cur][s ^ column], c2);
+            const bool bit = flp <= stay;
+            s_p[cur ^ 1][s] = bit ? flp : stay;
+            unsigned long long bal = __ballot(bit);
+            if (lane == 0) *(unsigned long long *)(E.path + (size_t)index * 32 + wv * 2) = bal;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const int mb = E.message[i2] ? 1 : 0;
+        float v = s < 512 ? s_p[cur][2 * s + mb] : inf;
+        __syncthreads();
+        s_p[cur][s] = v;
+        if (m - i2 <= hgt) colmask >>= 1;
+        __syncthreads();
+    }
+    if (s == 0) {
+        double totalprice = s_p[cur][0];
+        E.hdr[2] = (totalprice >= total) ? 0 : -2;     /* -2: forward ok, backward pending */
+    }
+    (void)n;
+}
+
+__global__ void __launch_bounds__(64) k_stc_backward(EmbedDev E)
+{
+    __shared__ unsigned s_path[64][32];
+    __shared__ uint8_t s_out[64];
+    const int lane = threadIdx.x;
+    const int n = E.hdr[0], m = E.hdr[1];
+    int nf = 0, done_upto = 0;             /* elements [0, done_upto) got their stego bit here */
+    if (E.hdr[2] == -2) {
+        const int hgt = 10;
+        const unsigned wshort = E.cols[64], wlong = E.cols[65];
+        int index = E.hdr[4] - 1;
+        done_upto = E.hdr[4];
+        unsigned state = 0, colmask = 0;
+        int i2 = m - 1, k = (E.blk_which[i2] ? (int)wlong : (int)wshort) - 1;
+        while (index >= 0) {
+            /* stage the path rows of elements [base, index] in LDS, then walk them serially */
+            const int base = index >= 63 ? index - 63 : 0, cnt = index - base + 1;
+            for (int i = lane; i < cnt * 32; i += 64) s_path[i >> 5][i & 31] = E.path[(size_t)base * 32 + i];
+            __syncthreads();
+            if (lane == 0) {
+                for (int e = cnt - 1; e >= 0; e--) {
+                    const int which = E.blk_which[i2];
+                    const int width = which ? (int)wlong : (int)wshort;
+                    if (k == width - 1) {
+                        state = (state << 1) | E.message[i2];
+                        if (m - i2 <= hgt) colmask = (colmask << 1) | 1;
+                    }
+                    if (s_path[e][state >> 5] & (1u << (state & 31))) { s_out[e] = 1; state ^= E.cols[which * 32 + k] & colmask; }
+                    else s_out[e] = 0;
+                    if (--k < 0) { i2--; if (i2 >= 0) k = (E.blk_which[i2] ? (int)wlong : (int)wshort) - 1; }
+                }
+            }
+            __syncthreads();
+            if (lane < cnt) {       /* stego bit and flip map (encoder.c:1848-1855) of this chunk */
+                int st = s_out[lane], f = E.cover[base + lane] ^ st;
+                E.stego[base + lane] = (uint8_t)st; E.flip[base + lane] = (int8_t)f; nf += f;
+            }
+            __syncthreads();
+            index = base - 1;
+        }
+    }
+    /* everything not reached by the Viterbi (failure, m == 0, tail) keeps stego = 0: flip = cover */
+    for (int i = done_upto + lane; i < n; i += 64) { int f = E.cover[i]; E.flip[i] = (int8_t)f; nf += f; }
+    nf = wave_sum_all(nf);
+    if (lane == 0) { E.hdr[3] = nf; E.hdr[2] = E.hdr[2] == -2 ? 1 : 0; }
+}
+#endif

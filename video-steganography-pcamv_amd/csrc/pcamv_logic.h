@@ -1,0 +1,855 @@
+/*
+ * pcamv_logic.h -- wave-uniform control code of the P-frame analysis: neighbour context and MV
+ * prediction, integer/sub-pel motion search, partition decision, P_SKIP probe, macroblock
+ * re-encode and the replacement-MV ("RCA") cost.  One wavefront runs this for one macroblock:
+ * every value here is wave-uniform, the per-pixel work is in the prim_* functions
+ * (pcamv_prims_gpu.h: lane-parallel; pcamv_prims_emu.h: scalar, used only by tests/ to run this
+ * same control code on the CPU).
+ *
+ * Reference behaviour restated (file:line of /root/reference):
+ *   mb_load            common/macroblock.c:914-1238, encoder/analyse.c:268-318
+ *   predict_mv*        common/macroblock.c:28-163, 388-470
+ *   me_search          encoder/me.c:158-666       refine_subpel  encoder/me.c:715-843
+ *   analyse_*          encoder/analyse.c:1122-1693, 2613-2827, 3518-3689
+ *   probe_pskip        encoder/macroblock.c:809-895
+ *   mb_encode          encoder/macroblock.c:277-372, 484-802
+ *   rca_mv_cost        encoder/analyse.c:2364-2550
+ */
+#ifndef PCAMV_LOGIC_H
+#define PCAMV_LOGIC_H
+#include "pcamv_common.h"
+
+/* ---------------------------------------------------------------- neighbour context */
+PCAMV_DEV void cache_mv_set(MBLocal *L, int x, int y, int w, int h, int mvx, int mvy)
+{
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            L->cmv[SCAN8_0 + x + i + 8 * (y + j)][0] = (int16_t)mvx;
+            L->cmv[SCAN8_0 + x + i + 8 * (y + j)][1] = (int16_t)mvy;
+        }
+}
+PCAMV_DEV void cache_ref_set(MBLocal *L, int x, int y, int w, int h, int ref)
+{
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) L->cref[SCAN8_0 + x + i + 8 * (y + j)] = (int8_t)ref;
+}
+
+PCAMV_DEV void predict_from3(int ref, int refa, int refb, int refc, const int16_t *a, const int16_t *b, const int16_t *c, int mvp[2])
+{
+    int cnt = (refa == ref) + (refb == ref) + (refc == ref);
+    if (cnt > 1) { mvp[0] = median3i(a[0], b[0], c[0]); mvp[1] = median3i(a[1], b[1], c[1]); }
+    else if (cnt == 1) {
+        const int16_t *s = refa == ref ? a : refb == ref ? b : c;
+        mvp[0] = s[0]; mvp[1] = s[1];
+    } else if (refb == -2 && refc == -2 && refa != -2) { mvp[0] = a[0]; mvp[1] = a[1]; }
+    else { mvp[0] = median3i(a[0], b[0], c[0]); mvp[1] = median3i(a[1], b[1], c[1]); }
+}
+PCAMV_DEV void predict_mv(MBLocal *L, int idx, int width, int mvp[2])
+{
+    int i8 = scan8_of(idx);
+    int ref = L->cref[i8];
+    int refa = L->cref[i8 - 1], refb = L->cref[i8 - 8], refc = L->cref[i8 - 8 + width];
+    const int16_t *a = L->cmv[i8 - 1], *b = L->cmv[i8 - 8], *c = L->cmv[i8 - 8 + width];
+    if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || refc == -2) { refc = L->cref[i8 - 8 - 1]; c = L->cmv[i8 - 8 - 1]; }
+    if (L->i_partition == PCAMV_D_16x8) {
+        if (idx == 0 && refb == ref) { mvp[0] = b[0]; mvp[1] = b[1]; return; }
+        if (idx != 0 && refa == ref) { mvp[0] = a[0]; mvp[1] = a[1]; return; }
+    } else if (L->i_partition == PCAMV_D_8x16) {
+        if (idx == 0 && refa == ref) { mvp[0] = a[0]; mvp[1] = a[1]; return; }
+        if (idx != 0 && refc == ref) { mvp[0] = c[0]; mvp[1] = c[1]; return; }
+    }
+    predict_from3(ref, refa, refb, refc, a, b, c, mvp);
+}
+PCAMV_DEV void predict_mv_16x16(MBLocal *L, int ref, int mvp[2])
+{
+    int refa = L->cref[SCAN8_0 - 1], refb = L->cref[SCAN8_0 - 8], refc = L->cref[SCAN8_0 - 8 + 4];
+    const int16_t *a = L->cmv[SCAN8_0 - 1], *b = L->cmv[SCAN8_0 - 8], *c = L->cmv[SCAN8_0 - 8 + 4];
+    if (refc == -2) { refc = L->cref[SCAN8_0 - 8 - 1]; c = L->cmv[SCAN8_0 - 8 - 1]; }
+    predict_from3(ref, refa, refb, refc, a, b, c, mvp);
+}
+PCAMV_DEV void predict_mv_pskip(MBLocal *L, int mv[2])
+{
+    int refa = L->cref[SCAN8_0 - 1], refb = L->cref[SCAN8_0 - 8];
+    const int16_t *a = L->cmv[SCAN8_0 - 1], *b = L->cmv[SCAN8_0 - 8];
+    if (refa == -2 || refb == -2 || !(refa | a[0] | a[1]) || !(refb | b[0] | b[1])) { mv[0] = mv[1] = 0; }
+    else predict_mv_16x16(L, 0, mv);
+}
+/* candidate MVs for the 16x16 search: spatial 16x16 results of non-skipped neighbours, then the
+ * co-located / right / below MVs of the previous frame scaled by POC distance */
+PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int mvc[9][2])
+{
+    int i = 0, xy = L->mb_xy, top = xy - F.mb_w;
+#define SETMV(mb) { mvc[i][0] = F.mvr[2 * (mb)]; mvc[i][1] = F.mvr[2 * (mb) + 1]; i++; }
+    if ((L->neighbour & NB_LEFT) && F.mb_type[xy - 1] != PCAMV_P_SKIP) SETMV(xy - 1);
+    if (L->neighbour & NB_TOP) {
+        if (F.mb_type[top] != PCAMV_P_SKIP) SETMV(top);
+        if ((L->neighbour & NB_TOPLEFT) && F.mb_type[top - 1] != PCAMV_P_SKIP) SETMV(top - 1);
+        if (L->mb_x < F.mb_w - 1 && F.mb_type[top + 1] != PCAMV_P_SKIP) SETMV(top + 1);
+    }
+#undef SETMV
+    if (F.have_prev) {
+        for (int k = 0; k < 3; k++) {
+            int dx = k == 1, dy = k == 2;
+            if (k == 1 && !(L->mb_x < F.mb_w - 1)) continue;
+            if (k == 2 && !(L->mb_y < F.mb_h - 1)) continue;
+            int b4 = 4 * (L->mb_y * 4 * F.mb_w + L->mb_x) + dx * 4 + dy * 4 * (4 * F.mb_w);
+            int b8 = 2 * (L->mb_y * 2 * F.mb_w + L->mb_x) + dx * 2 + dy * 2 * (2 * F.mb_w);
+            if (F.prev_ref[b8] >= 0) {
+                mvc[i][0] = (int16_t)((F.prev_mv[2 * b4] * F.tscale + 128) >> 8);
+                mvc[i][1] = (int16_t)((F.prev_mv[2 * b4 + 1] * F.tscale + 128) >> 8);
+                i++;
+            }
+        }
+    }
+    return i;
+}
+
+PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
+{
+    L->mb_x = mb_x; L->mb_y = mb_y; L->mb_xy = mb_y * F.mb_w + mb_x;
+    L->b_skip_mc = 0;
+    L->neighbour = 0;
+    L->type_left = L->type_top = L->type_topleft = L->type_topright = -1;
+    int top = L->mb_xy - F.mb_w;
+    if (mb_y > 0) { L->neighbour |= NB_TOP; L->type_top = F.mb_type[top]; }
+    if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = F.mb_type[L->mb_xy - 1]; }
+    if (mb_x < F.mb_w - 1 && mb_y > 0) { L->neighbour |= NB_TOPRIGHT; L->type_topright = F.mb_type[top + 1]; }
+    if (mb_x > 0 && mb_y > 0) { L->neighbour |= NB_TOPLEFT; L->type_topleft = F.mb_type[top - 1]; }
+    for (int i = 0; i < 48; i++) { L->cref[i] = -2; L->cmv[i][0] = 0; L->cmv[i][1] = 0; }
+    int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
+    int b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+    int t4 = (4 * (mb_y - 1) + 3) * s4 + 4 * mb_x, t8 = (2 * (mb_y - 1) + 1) * s8 + 2 * mb_x;
+    if (L->neighbour & NB_TOPLEFT) {
+        L->cref[SCAN8_0 - 1 - 8] = F.ref8[t8 - 1];
+        L->cmv[SCAN8_0 - 1 - 8][0] = F.mv[2 * (t4 - 1)]; L->cmv[SCAN8_0 - 1 - 8][1] = F.mv[2 * (t4 - 1) + 1];
+    }
+    if (L->neighbour & NB_TOP)
+        for (int i = 0; i < 4; i++) {
+            L->cref[SCAN8_0 - 8 + i] = F.ref8[t8 + (i >> 1)];
+            L->cmv[SCAN8_0 - 8 + i][0] = F.mv[2 * (t4 + i)]; L->cmv[SCAN8_0 - 8 + i][1] = F.mv[2 * (t4 + i) + 1];
+        }
+    if (L->neighbour & NB_TOPRIGHT) {
+        L->cref[SCAN8_0 + 4 - 8] = F.ref8[t8 + 2];
+        L->cmv[SCAN8_0 + 4 - 8][0] = F.mv[2 * (t4 + 4)]; L->cmv[SCAN8_0 + 4 - 8][1] = F.mv[2 * (t4 + 4) + 1];
+    }
+    if (L->neighbour & NB_LEFT)
+        for (int i = 0; i < 4; i++) {
+            L->cref[SCAN8_0 - 1 + 8 * i] = F.ref8[b8 - 1 + (i >> 1) * s8];
+            L->cmv[SCAN8_0 - 1 + 8 * i][0] = F.mv[2 * (b4 - 1 + i * s4)]; L->cmv[SCAN8_0 - 1 + 8 * i][1] = F.mv[2 * (b4 - 1 + i * s4) + 1];
+        }
+    int pm[2];
+    predict_mv_pskip(L, pm);
+    L->pskip_mv[0] = (int16_t)pm[0]; L->pskip_mv[1] = (int16_t)pm[1];
+
+    int fmv = 4 * F.mv_range;
+    L->mv_min[0] = 4 * (-16 * mb_x - 24);
+    L->mv_max[0] = 4 * (16 * (F.mb_w - mb_x - 1) + 24);
+    L->mv_min_spel[0] = clip3i(L->mv_min[0], -fmv, fmv - 1);
+    L->mv_max_spel[0] = clip3i(L->mv_max[0], -fmv, fmv - 1);
+    L->mv_min_fpel[0] = (L->mv_min_spel[0] >> 2) + 5;
+    L->mv_max_fpel[0] = (L->mv_max_spel[0] >> 2) - 5;
+    L->mv_min[1] = 4 * (-16 * mb_y - 24);
+    L->mv_max[1] = 4 * (16 * (F.mb_h - mb_y - 1) + 24);
+    L->mv_min_spel[1] = clip3i(L->mv_min[1], imax(4 * (-512 + 8), -fmv), fmv);
+    L->mv_max_spel[1] = clip3i(L->mv_max[1], -fmv, fmv - 1);
+    L->mv_max_spel[1] = imin(L->mv_max_spel[1], fmv * 4);
+    L->mv_min_fpel[1] = (L->mv_min_spel[1] >> 2) + 5;
+    L->mv_max_fpel[1] = (L->mv_max_spel[1] >> 2) - 5;
+    prim_load_fenc(F, L);
+}
+
+/* ---------------------------------------------------------------- motion search */
+PCAMV_CONST int subpel_iter_tab[10][4] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {0, 2, 1, 1},
+                                          {0, 2, 1, 2}, {0, 0, 2, 2}, {0, 0, 2, 2}, {0, 0, 4, 10}, {0, 0, 4, 10}};
+PCAMV_CONST int mod6m1_tab[8] = {5, 0, 1, 2, 3, 4, 5, 0};
+PCAMV_CONST int hex2_tab[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
+PCAMV_CONST int hex4_tab[16][2] = {{-4, 2}, {-4, 1}, {-4, 0}, {-4, -1}, {-4, -2}, {4, -2}, {4, -1}, {4, 0},
+                                   {4, 1},  {4, 2},  {2, 3},  {0, 4},   {-2, 3},  {-2, -3}, {0, -4}, {2, -3}};
+PCAMV_CONST int range_mul_tab[4][4] = {{3, 3, 4, 4}, {3, 4, 4, 4}, {4, 4, 4, 5}, {4, 4, 5, 6}};
+PCAMV_CONST int size_shift_tab[7] = {0, 1, 1, 2, 3, 3, 4};
+
+struct SearchCtx {
+    const FrameDev *F; MBLocal *L; MEState *me;
+    int bmx, bmy, bcost;
+};
+#define MVCOSTX(v) ((int)F.cost_mv[(v) - me->mvp[0]])
+#define MVCOSTY(v) ((int)F.cost_mv[(v) - me->mvp[1]])
+
+/* up to 4 full-pel candidates at once; costs include the MV bits; best updated in order (strict <) */
+PCAMV_DEV void fpel_try(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
+                        const int *mx, const int *my, int n, int *costs_out)
+{
+    int c[4];
+    prim_sad_fpel_xn(F, L, me->i_pixel, me->xoff, me->yoff, mx, my, n, c);
+    for (int k = 0; k < n; k++) {
+        c[k] += MVCOSTX(mx[k] << 2) + MVCOSTY(my[k] << 2);
+        if (costs_out) costs_out[k] = c[k];
+        else if (c[k] < bcost) { bcost = c[k]; bmx = mx[k]; bmy = my[k]; }
+    }
+}
+#define TRY1(X, Y) { int tx_[1] = {X}, ty_[1] = {Y}; fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 1, 0); }
+#define TRY4(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1) { \
+        int tx_[4] = {(ox) + (a0), (ox) + (b0), (ox) + (c0), (ox) + (d0)}, ty_[4] = {(oy) + (a1), (oy) + (b1), (oy) + (c1), (oy) + (d1)}; \
+        fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 4, 0); }
+#define CHECK_MVRANGE(mx, my) ((mx) >= mv_x_min && (mx) <= mv_x_max && (my) >= mv_y_min && (my) <= mv_y_max)
+
+/* qpel-precision cost of one candidate with the conditional chroma terms of COST_MV_SATD */
+PCAMV_DEV int qpel_cost_with_chroma(const FrameDev &F, MBLocal *L, MEState *me, int luma_cost, int mx, int my, int bcost, int b_chroma_me)
+{
+    int cost = luma_cost;
+    if (b_chroma_me && cost < bcost) {
+        int cu, cv;
+        prim_cost_chroma_uv(F, L, L->fenc, me->i_pixel, me->xoff, me->yoff, mx, my, F.subme > 1, &cu, &cv);
+        cost += cu;
+        if (cost < bcost) cost += cv;
+    }
+    return cost;
+}
+
+PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpel_iters, int qpel_iters, int b_refine_qpel)
+{
+    const int ip = me->i_pixel;
+    const int b_chroma_me = F.b_chroma_me && ip <= PIX_8x8;
+    const int satd = F.subme > 1;
+    int bmx = me->mv[0], bmy = me->mv[1], bcost = me->cost, odir = -1, bdir;
+    if (hpel_iters && F.subme < 3) {
+        int mx = clip3i(me->mvp[0], L->mv_min_spel[0], L->mv_max_spel[0]);
+        int my = clip3i(me->mvp[1], L->mv_min_spel[1], L->mv_max_spel[1]);
+        if ((mx - bmx) | (my - bmy)) {
+            int c = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, mx, my, 0) + MVCOSTX(mx) + MVCOSTY(my);
+            if (c < bcost) { bcost = c; bmx = mx; bmy = my; }
+        }
+    }
+    for (int i = hpel_iters; i > 0; i--) {
+        int omx = bmx, omy = bmy, c[4];
+        int cx[4] = {omx, omx, omx - 2, omx + 2}, cy[4] = {omy - 2, omy + 2, omy, omy};
+        prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, 0, c);
+        c[0] += MVCOSTX(omx) + MVCOSTY(omy - 2); if (c[0] < bcost) { bcost = c[0]; bmy = omy - 2; }
+        c[1] += MVCOSTX(omx) + MVCOSTY(omy + 2); if (c[1] < bcost) { bcost = c[1]; bmy = omy + 2; }
+        c[2] += MVCOSTX(omx - 2) + MVCOSTY(omy); if (c[2] < bcost) { bcost = c[2]; bmx = omx - 2; bmy = omy; }
+        c[3] += MVCOSTX(omx + 2) + MVCOSTY(omy); if (c[3] < bcost) { bcost = c[3]; bmx = omx + 2; bmy = omy; }
+        if (bmx == omx && bmy == omy) break;
+    }
+    if (!b_refine_qpel) {
+        if (bmy > L->mv_max_spel[1]) bmy = L->mv_max_spel[1];
+        bcost = PCAMV_COST_MAX;
+        int lc = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, bmx, bmy, satd) + MVCOSTX(bmx) + MVCOSTY(bmy);
+        int c = qpel_cost_with_chroma(F, L, me, lc, bmx, bmy, bcost, b_chroma_me);
+        if (c < bcost) bcost = c;
+    }
+    bdir = -1;
+    for (int i = qpel_iters; i > 0; i--) {
+        odir = bdir;
+        int omx = bmx, omy = bmy, lc[4];
+        int cx[4] = {omx, omx, omx - 1, omx + 1}, cy[4] = {omy - 1, omy + 1, omy, omy};
+        prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, satd, lc);
+        for (int k = 0; k < 4; k++) {
+            if (!(b_refine_qpel || (k ^ 1) != odir)) continue;
+            int l = lc[k] + MVCOSTX(cx[k]) + MVCOSTY(cy[k]);
+            int c = qpel_cost_with_chroma(F, L, me, l, cx[k], cy[k], bcost, b_chroma_me);
+            if (c < bcost) { bcost = c; bmx = cx[k]; bmy = cy[k]; bdir = k; }
+        }
+        if (bmx == omx && bmy == omy) break;
+    }
+    if (bmy > L->mv_max_spel[1]) {
+        bmy = L->mv_max_spel[1];
+        bcost = PCAMV_COST_MAX;
+        int lc = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, bmx, bmy, satd) + MVCOSTX(bmx) + MVCOSTY(bmy);
+        int c = qpel_cost_with_chroma(F, L, me, lc, bmx, bmy, bcost, b_chroma_me);
+        if (c < bcost) bcost = c;
+    }
+    me->cost = bcost; me->mv[0] = bmx; me->mv[1] = bmy;
+    me->cost_mv = MVCOSTX(bmx) + MVCOSTY(bmy);
+}
+
+PCAMV_DEV void cross_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
+                            int omx, int omy, int start, int x_max, int y_max,
+                            int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
+{
+    int i = start;
+    if (x_max <= imin(mv_x_max - omx, omx - mv_x_min))
+        for (; i < x_max - 2; i += 4) TRY4(omx, omy, i, 0, -i, 0, i + 2, 0, -i - 2, 0);
+    for (; i < x_max; i += 2) {
+        if (omx + i <= mv_x_max) TRY1(omx + i, omy);
+        if (omx - i >= mv_x_min) TRY1(omx - i, omy);
+    }
+    i = start;
+    if (y_max <= imin(mv_y_max - omy, omy - mv_y_min))
+        for (; i < y_max - 2; i += 4) TRY4(omx, omy, 0, i, 0, -i, 0, i + 2, 0, -i - 2);
+    for (; i < y_max; i += 2) {
+        if (omy + i <= mv_y_max) TRY1(omx, omy + i);
+        if (omy - i >= mv_y_min) TRY1(omx, omy - i);
+    }
+}
+
+PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int i_me_range,
+                          int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
+{
+    int costs[6], dir = -2;
+    {
+        int tx[4] = {bmx - 2, bmx - 1, bmx + 1, bmx + 2}, ty[4] = {bmy, bmy + 2, bmy + 2, bmy};
+        int ux[2] = {bmx + 1, bmx - 1}, uy[2] = {bmy - 2, bmy - 2};
+        fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 4, costs);
+        fpel_try(F, L, me, bmx, bmy, bcost, ux, uy, 2, costs + 4);
+    }
+    for (int i = 0; i < 6; i++) if (costs[i] < bcost) { bcost = costs[i]; dir = i; }
+    if (dir != -2) {
+        bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
+        for (int i = 1; i < i_me_range / 2 && CHECK_MVRANGE(bmx, bmy); i++) {
+            const int odir = mod6m1_tab[dir + 1];
+            int tx[3] = {bmx + hex2_tab[odir][0], bmx + hex2_tab[odir + 1][0], bmx + hex2_tab[odir + 2][0]};
+            int ty[3] = {bmy + hex2_tab[odir][1], bmy + hex2_tab[odir + 1][1], bmy + hex2_tab[odir + 2][1]};
+            fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 3, costs);
+            dir = -2;
+            if (costs[0] < bcost) { bcost = costs[0]; dir = odir - 1; }
+            if (costs[1] < bcost) { bcost = costs[1]; dir = odir; }
+            if (costs[2] < bcost) { bcost = costs[2]; dir = odir + 1; }
+            if (dir == -2) break;
+            bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
+        }
+    }
+    int omx = bmx, omy = bmy;
+    TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
+    TRY4(omx, omy, -1, -1, -1, 1, 1, -1, 1, 1);
+}
+
+PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc)
+{
+    const int ip = me->i_pixel;
+    int i_me_range = F.me_range;
+    int bmx, bmy, bcost, bpred_mx = 0, bpred_my = 0, bpred_cost = PCAMV_COST_MAX, omx, omy, pmx, pmy;
+    const int mv_x_min = L->mv_min_fpel[0], mv_y_min = L->mv_min_fpel[1], mv_x_max = L->mv_max_fpel[0], mv_y_max = L->mv_max_fpel[1];
+
+    bmx = clip3i(me->mvp[0], mv_x_min * 4, mv_x_max * 4);
+    bmy = clip3i(me->mvp[1], mv_y_min * 4, mv_y_max * 4);
+    pmx = (bmx + 2) >> 2; pmy = (bmy + 2) >> 2;
+    bcost = PCAMV_COST_MAX;
+
+    if (F.subme >= 3) {
+        /* qpel-precision test of the predictor and the candidates (plain SAD) */
+        int cx[10], cy[10], n = 0, sx = bmx, sy = bmy;
+        cx[n] = bmx; cy[n] = bmy; n++;
+        for (int i = 0; i < i_mvc; i++)
+            if ((mvc[i][0] | mvc[i][1]) && ((sx - mvc[i][0]) | (sy - mvc[i][1]))) {
+                cx[n] = clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4);
+                cy[n] = clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4);
+                n++;
+            }
+        for (int b = 0; b < n; b += 4) {
+            int c[4], nn = imin(4, n - b);
+            prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx + b, cy + b, nn, 0, c);
+            for (int k = 0; k < nn; k++) {
+                int cc = c[k] + MVCOSTX(cx[b + k]) + MVCOSTY(cy[b + k]);
+                if (cc < bpred_cost) { bpred_cost = cc; bpred_mx = cx[b + k]; bpred_my = cy[b + k]; }
+            }
+        }
+        bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
+        TRY1(bmx, bmy);
+    } else {
+        TRY1(pmx, pmy);
+        bcost -= MVCOSTX(pmx << 2) + MVCOSTY(pmy << 2);
+        for (int i = 0; i < i_mvc; i++) {
+            int mx = (mvc[i][0] + 2) >> 2, my = (mvc[i][1] + 2) >> 2;
+            if ((mx | my) && ((mx - bmx) | (my - bmy))) {
+                mx = clip3i(mx, mv_x_min, mv_x_max); my = clip3i(my, mv_y_min, mv_y_max);
+                TRY1(mx, my);
+            }
+        }
+    }
+    TRY1(0, 0);
+
+    if (F.me_method == PCAMV_ME_DIA) {
+        int i = 0;
+        do {
+            omx = bmx; omy = bmy;
+            TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
+            if ((bmx == omx) & (bmy == omy)) break;
+            if (!CHECK_MVRANGE(bmx, bmy)) break;
+        } while (++i < i_me_range);
+    } else if (F.me_method == PCAMV_ME_HEX) {
+        hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+    } else { /* UMH */
+        int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
+#define SAD_THRESH(v) (bcost < ((v) >> size_shift_tab[ip]))
+        ucost1 = bcost;
+        TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0);
+        if (pmx | pmy) TRY4(0, 0, 0, -1, 0, 1, -1, 0, 1, 0);
+        if (ip != PIX_4x4) {
+            ucost2 = bcost;
+            if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) { omx = bmx; omy = bmy; TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0); }
+            if (bcost == ucost2) cross_start = 3;
+            omx = bmx; omy = bmy;
+            if (bcost == ucost2 && SAD_THRESH(2000)) {
+                TRY4(omx, omy, 0, -2, -1, -1, 1, -1, -2, 0);
+                TRY4(omx, omy, 2, 0, -1, 1, 1, 1, 0, 2);
+                if (bcost == ucost1 && SAD_THRESH(500)) { done = 1; do_hex = 0; }
+                else if (bcost == ucost2) {
+                    int range = (i_me_range >> 1) | 1;
+                    cross_search(F, L, me, bmx, bmy, bcost, omx, omy, 3, range, range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+                    TRY4(omx, omy, -1, -2, 1, -2, -2, -1, 2, -1);
+                    TRY4(omx, omy, -2, 1, 2, 1, -1, 2, 1, 2);
+                    if (bcost == ucost2) { done = 1; do_hex = 0; }
+                    cross_start = range + 2;
+                }
+            }
+            if (!done) {
+                if (i_mvc) {
+                    int mvd, sad_ctx, mvd_ctx, denom = 1;
+                    if (i_mvc == 1) {
+                        if (ip == PIX_16x16) mvd = 25;
+                        else mvd = iabs(me->mvp[0] - mvc[0][0]) + iabs(me->mvp[1] - mvc[0][1]);
+                    } else {
+                        denom = i_mvc - 1; mvd = 0;
+                        if (ip != PIX_16x16) { mvd = iabs(me->mvp[0] - mvc[0][0]) + iabs(me->mvp[1] - mvc[0][1]); denom++; }
+                        for (int i = 0; i < i_mvc - 1; i++) mvd += iabs(mvc[i][0] - mvc[i + 1][0]) + iabs(mvc[i][1] - mvc[i + 1][1]);
+                    }
+                    sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+                    mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                    i_me_range = i_me_range * range_mul_tab[mvd_ctx][sad_ctx] / 4;
+                }
+                cross_search(F, L, me, bmx, bmy, bcost, omx, omy, cross_start, i_me_range, i_me_range / 2, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+                TRY4(omx, omy, -2, -2, -2, 2, 2, -2, 2, 2);
+                omx = bmx; omy = bmy;
+                int i = 1;
+                do {
+                    if (4 * i > imin(imin(mv_x_max - omx, omx - mv_x_min), imin(mv_y_max - omy, omy - mv_y_min))) {
+                        for (int j = 0; j < 16; j++) {
+                            int mx = omx + hex4_tab[j][0] * i, my = omy + hex4_tab[j][1] * i;
+                            if (CHECK_MVRANGE(mx, my)) TRY1(mx, my);
+                        }
+                    } else {
+                        for (int j = 0; j < 16; j += 4) {
+                            int tx[4], ty[4];
+                            for (int k = 0; k < 4; k++) { tx[k] = omx + hex4_tab[j + k][0] * i; ty[k] = omy + hex4_tab[j + k][1] * i; }
+                            fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 4, 0);
+                        }
+                    }
+                } while (++i <= i_me_range / 4);
+                if (!(bmy <= mv_y_max)) do_hex = 0;
+            }
+        }
+        if (do_hex) hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+#undef SAD_THRESH
+    }
+
+    if (bpred_cost < bcost) { me->mv[0] = bpred_mx; me->mv[1] = bpred_my; me->cost = bpred_cost; }
+    else { me->mv[0] = bmx << 2; me->mv[1] = bmy << 2; me->cost = bcost; }
+    me->cost_mv = MVCOSTX(me->mv[0]) + MVCOSTY(me->mv[1]);
+    if (bmx == pmx && bmy == pmy && F.subme < 3) me->cost += me->cost_mv;
+    if (F.subme >= 2) refine_subpel(F, L, me, subpel_iter_tab[F.subme][2], subpel_iter_tab[F.subme][3], 0);
+    else if (me->mv[1] > L->mv_max_spel[1]) me->mv[1] = L->mv_max_spel[1];
+}
+
+PCAMV_DEV void me_refine_qpel(const FrameDev &F, MBLocal *L, MEState *me)
+{
+    refine_subpel(F, L, me, subpel_iter_tab[F.subme][0], subpel_iter_tab[F.subme][1], 1);
+}
+
+/* ---------------------------------------------------------------- macroblock (re-)encode */
+/* sequential-equivalent decimation of a 4x4 scan: done per block by prim_residual (blk_score) */
+PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L)
+{
+    if (L->i_type == PCAMV_P_SKIP) {
+        if (!L->b_skip_mc) {
+            int mvx = clip3i(L->cmv[SCAN8_0][0], L->mv_min[0], L->mv_max[0]);
+            int mvy = clip3i(L->cmv[SCAN8_0][1], L->mv_min[1], L->mv_max[1]);
+            prim_predict_16x16(F, L, mvx, mvy, 1);
+        }
+        L->cbp_luma = L->cbp_chroma = 0;
+        return;
+    }
+    if (!L->b_skip_mc) prim_predict_mb(F, L);
+    prim_residual(F, L, 1, 1);
+    /* luma 8x8 / MB decimation (encoder/macroblock.c:696-753) */
+    unsigned keep = 0; int cbp = 0, decimate_mb = 0;
+    for (int i8 = 0; i8 < 4; i8++) {
+        int dec8 = 0, any = 0;
+        for (int i4 = 0; i4 < 4; i4++) {
+            int idx = i8 * 4 + i4;
+            if (L->blk_nz[idx]) { if (F.b_dct_decimate && dec8 < 6) dec8 += L->blk_score[idx]; any = 1; }
+        }
+        decimate_mb += dec8;
+        if (F.b_dct_decimate) { if (dec8 >= 4) cbp |= 1 << i8; }
+        else if (any) cbp |= 1 << i8;
+    }
+    if (F.b_dct_decimate && decimate_mb < 6) cbp = 0;
+    for (int i8 = 0; i8 < 4; i8++) if (cbp & (1 << i8)) keep |= 0xFu << (4 * i8);
+    L->cbp_luma = cbp;
+    /* chroma (encoder/macroblock.c:277-372) */
+    int cmode[2], any_ac = 0;
+    for (int ch = 0; ch < 2; ch++) {
+        int score = 0, nz_ac = 0, nz_dc = 0;
+        for (int i = 0; i < 4; i++) if (L->blk_nz[16 + ch * 4 + i]) { nz_ac = 1; if (F.b_dct_decimate) score += L->blk_score[16 + ch * 4 + i]; }
+        int dc[4];
+        { int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1;
+          for (int k = 0; k < 4; k++) {
+              int c = L->cdc[ch][k];
+              dc[k] = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+              nz_dc |= dc[k];
+          } }
+        int d0 = dc[0] + dc[1], d1 = dc[2] + dc[3], d2 = dc[0] - dc[1], d3 = dc[2] - dc[3];
+        int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        int r0 = (int16_t)((d0 + d1) * dmf >> -qbits), r1 = (int16_t)((d0 - d1) * dmf >> -qbits);
+        int r2 = (int16_t)((d2 + d3) * dmf >> -qbits), r3 = (int16_t)((d2 - d3) * dmf >> -qbits);
+        if ((F.b_dct_decimate && score < 7) || !nz_ac) {
+            if (!nz_dc) { cmode[ch] = 0; continue; }
+            cmode[ch] = 1;
+            L->cdc[ch][0] = (int16_t)r0; L->cdc[ch][1] = (int16_t)r1; L->cdc[ch][2] = (int16_t)r2; L->cdc[ch][3] = (int16_t)r3;
+        } else {
+            any_ac = 1; cmode[ch] = 2;
+            if (nz_dc) {
+                L->coef[16 + ch * 4 + 0][0] = (int16_t)r0; L->coef[16 + ch * 4 + 1][0] = (int16_t)r1;
+                L->coef[16 + ch * 4 + 2][0] = (int16_t)r2; L->coef[16 + ch * 4 + 3][0] = (int16_t)r3;
+            }
+        }
+    }
+    L->cbp_chroma = any_ac ? 2 : 0;
+    prim_add_idct(F, L, keep, cmode[0], cmode[1]);
+}
+
+PCAMV_DEV int probe_pskip(const FrameDev &F, MBLocal *L)
+{
+    int mvx = clip3i(L->pskip_mv[0], L->mv_min[0], L->mv_max[0]);
+    int mvy = clip3i(L->pskip_mv[1], L->mv_min[1], L->mv_max[1]);
+    prim_predict_16x16(F, L, mvx, mvy, 0);
+    prim_residual(F, L, 1, 0);
+    int decimate = 0;
+    for (int idx = 0; idx < 16; idx++) if (L->blk_nz[idx]) { decimate += L->blk_score[idx]; if (decimate >= 6) return 0; }
+    int thresh = (F.lambda2_chroma + 32) >> 6;
+    prim_predict_16x16(F, L, mvx, mvy, 2);
+    int need[2];
+    for (int ch = 0; ch < 2; ch++) need[ch] = !(prim_chroma_ssd(F, L, ch) < thresh);
+    if (need[0] | need[1]) prim_residual(F, L, 0, 1);
+    for (int ch = 0; ch < 2; ch++) {
+        if (!need[ch]) continue;
+        int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1, nz = 0;
+        for (int k = 0; k < 4; k++) {
+            int c = L->cdc[ch][k];
+            nz |= c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+        }
+        if (nz) return 0;
+        decimate = 0;
+        for (int i = 0; i < 4; i++) if (L->blk_nz[16 + ch * 4 + i]) { decimate += L->blk_score[16 + ch * 4 + i]; if (decimate >= 7) return 0; }
+    }
+    L->b_skip_mc = 1;
+    return 1;
+}
+
+/* ---------------------------------------------------------------- partition analysis */
+struct Analysis {
+    MEState me16x16, me8x8[4], me16x8[2], me8x16[2];
+    MEState me4x4[4][4], me8x4[4][2], me4x8[4][2];
+    int mvc[5][2];
+    int cost8x8, cost16x8, cost8x16, cost4x4[4], cost8x4[4], cost4x8[4];
+};
+PCAMV_DEV void me_setup(MEState *me, int ip, int xoff, int yoff) { me->i_pixel = ip; me->xoff = xoff; me->yoff = yoff; me->cost = me->cost_mv = me->cost_rec = 0; me->mv[0] = me->mv[1] = 0; me->mvp[0] = me->mvp[1] = 0; }
+
+PCAMV_DEV void cache_mv_p8x8(MBLocal *L, Analysis *a, int i)
+{
+    int x = 2 * (i % 2), y = 2 * (i / 2);
+    switch (L->sub_part[i]) {
+    case PCAMV_D_L0_8x8: cache_mv_set(L, x, y, 2, 2, a->me8x8[i].mv[0], a->me8x8[i].mv[1]); break;
+    case PCAMV_D_L0_8x4: cache_mv_set(L, x, y, 2, 1, a->me8x4[i][0].mv[0], a->me8x4[i][0].mv[1]); cache_mv_set(L, x, y + 1, 2, 1, a->me8x4[i][1].mv[0], a->me8x4[i][1].mv[1]); break;
+    case PCAMV_D_L0_4x8: cache_mv_set(L, x, y, 1, 2, a->me4x8[i][0].mv[0], a->me4x8[i][0].mv[1]); cache_mv_set(L, x + 1, y, 1, 2, a->me4x8[i][1].mv[0], a->me4x8[i][1].mv[1]); break;
+    default:
+        cache_mv_set(L, x, y, 1, 1, a->me4x4[i][0].mv[0], a->me4x4[i][0].mv[1]); cache_mv_set(L, x + 1, y, 1, 1, a->me4x4[i][1].mv[0], a->me4x4[i][1].mv[1]);
+        cache_mv_set(L, x, y + 1, 1, 1, a->me4x4[i][2].mv[0], a->me4x4[i][2].mv[1]); cache_mv_set(L, x + 1, y + 1, 1, 1, a->me4x4[i][3].mv[0], a->me4x4[i][3].mv[1]); break;
+    }
+}
+PCAMV_DEV void update_cache(MBLocal *L, Analysis *a)
+{
+    if (L->i_type == PCAMV_P_L0) {
+        cache_ref_set(L, 0, 0, 4, 4, 0);
+        if (L->i_partition == PCAMV_D_16x16) cache_mv_set(L, 0, 0, 4, 4, a->me16x16.mv[0], a->me16x16.mv[1]);
+        else if (L->i_partition == PCAMV_D_16x8) { cache_mv_set(L, 0, 0, 4, 2, a->me16x8[0].mv[0], a->me16x8[0].mv[1]); cache_mv_set(L, 0, 2, 4, 2, a->me16x8[1].mv[0], a->me16x8[1].mv[1]); }
+        else if (L->i_partition == PCAMV_D_8x16) { cache_mv_set(L, 0, 0, 2, 4, a->me8x16[0].mv[0], a->me8x16[0].mv[1]); cache_mv_set(L, 2, 0, 2, 4, a->me8x16[1].mv[0], a->me8x16[1].mv[1]); }
+    } else if (L->i_type == PCAMV_P_8x8) {
+        cache_ref_set(L, 0, 0, 4, 4, 0);
+        for (int i = 0; i < 4; i++) cache_mv_p8x8(L, a, i);
+    } else {
+        L->i_partition = PCAMV_D_16x16;
+        cache_ref_set(L, 0, 0, 4, 4, 0);
+        cache_mv_set(L, 0, 0, 4, 4, L->pskip_mv[0], L->pskip_mv[1]);
+    }
+}
+
+PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_try_pskip)
+{
+    MEState me; int mvc[9][2];
+    me_setup(&me, PIX_16x16, 0, 0);
+    predict_mv_16x16(L, 0, me.mvp);
+    int i_mvc = predict_mv_ref16x16(F, L, mvc);
+    me_search(F, L, &me, mvc, i_mvc);
+    if (b_try_pskip && me.cost - me.cost_mv < 300 * F.lambda &&
+        iabs(me.mv[0] - L->pskip_mv[0]) + iabs(me.mv[1] - L->pskip_mv[1]) <= 1 && probe_pskip(F, L)) {
+        L->i_type = PCAMV_P_SKIP;
+        update_cache(L, a);
+        return 1;
+    }
+    a->me16x16 = me;
+    a->mvc[0][0] = me.mv[0]; a->mvc[0][1] = me.mv[1];
+    prim_store_mvr(F, L, me.mv[0], me.mv[1]);
+    cache_ref_set(L, 0, 0, 4, 4, 0);
+    L->i_type = PCAMV_P_L0;
+    return 0;
+}
+PCAMV_DEV void analyse_p8x8(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    int i_mvc = 1;
+    L->i_partition = PCAMV_D_8x8;
+    a->mvc[0][0] = a->me16x16.mv[0]; a->mvc[0][1] = a->me16x16.mv[1];
+    for (int i = 0; i < 4; i++) {
+        MEState *me = &a->me8x8[i];
+        int x8 = i % 2, y8 = i / 2;
+        me_setup(me, PIX_8x8, 8 * x8, 8 * y8);
+        predict_mv(L, 4 * i, 2, me->mvp);
+        me_search(F, L, me, a->mvc, i_mvc);
+        cache_mv_set(L, 2 * x8, 2 * y8, 2, 2, me->mv[0], me->mv[1]);
+        a->mvc[i_mvc][0] = me->mv[0]; a->mvc[i_mvc][1] = me->mv[1]; i_mvc++;
+        me->cost += F.lambda * 1;
+    }
+    a->cost8x8 = a->me8x8[0].cost + a->me8x8[1].cost + a->me8x8[2].cost + a->me8x8[3].cost;
+    for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
+}
+PCAMV_DEV void analyse_p16x8(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    L->i_partition = PCAMV_D_16x8;
+    for (int i = 0; i < 2; i++) {
+        MEState me; int mvc[3][2];
+        me_setup(&me, PIX_16x8, 0, 8 * i);
+        mvc[0][0] = a->mvc[0][0]; mvc[0][1] = a->mvc[0][1];
+        mvc[1][0] = a->mvc[2 * i + 1][0]; mvc[1][1] = a->mvc[2 * i + 1][1];
+        mvc[2][0] = a->mvc[2 * i + 2][0]; mvc[2][1] = a->mvc[2 * i + 2][1];
+        cache_ref_set(L, 0, 2 * i, 4, 2, 0);
+        predict_mv(L, 8 * i, 4, me.mvp);
+        me_search(F, L, &me, mvc, 3);
+        a->me16x8[i] = me;
+        cache_mv_set(L, 0, 2 * i, 4, 2, me.mv[0], me.mv[1]);
+    }
+    a->cost16x8 = a->me16x8[0].cost + a->me16x8[1].cost;
+}
+PCAMV_DEV void analyse_p8x16(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    L->i_partition = PCAMV_D_8x16;
+    for (int i = 0; i < 2; i++) {
+        MEState me; int mvc[3][2];
+        me_setup(&me, PIX_8x16, 8 * i, 0);
+        mvc[0][0] = a->mvc[0][0]; mvc[0][1] = a->mvc[0][1];
+        mvc[1][0] = a->mvc[i + 1][0]; mvc[1][1] = a->mvc[i + 1][1];
+        mvc[2][0] = a->mvc[i + 3][0]; mvc[2][1] = a->mvc[i + 3][1];
+        cache_ref_set(L, 2 * i, 0, 2, 4, 0);
+        predict_mv(L, 4 * i, 2, me.mvp);
+        me_search(F, L, &me, mvc, 3);
+        a->me8x16[i] = me;
+        cache_mv_set(L, 2 * i, 0, 2, 4, me.mv[0], me.mv[1]);
+    }
+    a->cost8x16 = a->me8x16[0].cost + a->me8x16[1].cost;
+}
+PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8, int pixel)
+{
+    L->i_partition = PCAMV_D_8x8;
+    int n = pixel == PIX_4x4 ? 4 : 2, cost = 0;
+    for (int k = 0; k < n; k++) {
+        int idx = 4 * i8 + (pixel == PIX_8x4 ? 2 * k : k);
+        MEState *me = pixel == PIX_4x4 ? &a->me4x4[i8][k] : pixel == PIX_8x4 ? &a->me8x4[i8][k] : &a->me4x8[i8][k];
+        me_setup(me, pixel, 4 * blk_x_tab[idx], 4 * blk_y_tab[idx]);
+        predict_mv(L, idx, pixel == PIX_8x4 ? 2 : 1, me->mvp);
+        int mvc[1][2];
+        const MEState *cand = pixel == PIX_4x4 ? &a->me8x8[i8] : &a->me4x4[i8][0];
+        mvc[0][0] = cand->mv[0]; mvc[0][1] = cand->mv[1];
+        me_search(F, L, me, mvc, k == 0);
+        cache_mv_set(L, blk_x_tab[idx], blk_y_tab[idx], pixel == PIX_8x4 ? 2 : 1, pixel == PIX_4x8 ? 2 : 1, me->mv[0], me->mv[1]);
+        cost += me->cost;
+    }
+    cost += F.lambda * (pixel == PIX_4x4 ? 5 : 3);
+    if (F.b_chroma_me) {
+        /* analyse.c:1535-1567: chroma of the 8x8 predicted with one MV per luma 4x4 */
+        int qx[4], qy[4];
+        for (int q = 0; q < 4; q++) {
+            const MEState *m4 = pixel == PIX_4x4 ? &a->me4x4[i8][q] : pixel == PIX_8x4 ? &a->me8x4[i8][q >> 1] : &a->me4x8[i8][q & 1];
+            qx[q] = m4->mv[0]; qy[q] = m4->mv[1];
+        }
+        cost += prim_chroma4x4_cost(F, L, i8, qx, qy, F.subme > 1);
+    }
+    if (pixel == PIX_4x4) a->cost4x4[i8] = cost; else if (pixel == PIX_8x4) a->cost8x4[i8] = cost; else a->cost4x8[i8] = cost;
+}
+
+/* SATD of the reconstruction against the reference at (mx,my): MV_SATD_FDEC_IH */
+PCAMV_DEV int mv_satd_rec(const FrameDev &F, MBLocal *L, MEState *me, int luma_cost, int mx, int my)
+{
+    int cost = luma_cost + MVCOSTX(mx) + MVCOSTY(my);
+    if (F.b_chroma_me && me->i_pixel <= PIX_8x8) {
+        int cu, cv;
+        prim_cost_chroma_uv(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, mx, my, F.subme > 1, &cu, &cv);
+        cost += cu + cv;
+    }
+    return cost;
+}
+PCAMV_CONST signed char d_mv_tab[12][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-2, 1}, {-1, 2}, {1, 2}, {2, 1}, {2, -1}, {1, -2}, {-1, -2}, {-2, -1}};
+PCAMV_CONST signed char d_nb_tab[9][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {0, 0}};
+
+/* nine neighbourhood costs around (cx,cy) on the current reconstruction; returns min, last in *last */
+PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, int cx, int cy, int *nb_cost, int *last)
+{
+    int mn = PCAMV_COST_MAX, c = 0;
+    int lc[12], qx[12], qy[12];
+    for (int k = 0; k < 9; k++) { qx[k] = cx + d_nb_tab[k][0]; qy[k] = cy + d_nb_tab[k][1]; }
+    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx, qy, 4, F.subme > 1, lc);
+    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx + 4, qy + 4, 4, F.subme > 1, lc + 4);
+    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx + 8, qy + 8, 1, F.subme > 1, lc + 8);
+    for (int k = 0; k < 9; k++) {
+        c = mv_satd_rec(F, L, me, lc[k], qx[k], qy[k]);
+        if (nb_cost) nb_cost[k] = c;
+        if (c < mn) mn = c;
+    }
+    *last = c;
+    return mn;
+}
+
+PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *me, int *m_x, int *m_y)
+{
+    const float beta1 = 1.4, beta2 = 4;
+    int bmx = me->mv[0], bmy = me->mv[1];
+    int cost = 0, min_cost, nb_cost[9];
+    int b_1_neighbor = 0, b_error_pos = 0;
+    update_cache(L, a); mb_encode(F, L); prim_copy_pred_to_rec(L);
+    min_cost = rca_nine(F, L, me, bmx, bmy, nb_cost, &cost);
+    me->cost_rec = nb_cost[8];
+    const int want_optimal = !(min_cost < me->cost_rec);
+    min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
+    int ii_best = -1;
+    for (int ii = 0; ii < 12; ii++) {
+        int bx1 = bmx + d_mv_tab[ii][0], by1 = bmy + d_mv_tab[ii][1];
+        me->mv[0] = bx1; me->mv[1] = by1;
+        update_cache(L, a); mb_encode(F, L); prim_copy_pred_to_rec(L);
+        int min1 = rca_nine(F, L, me, bx1, by1, 0, &cost);
+        int is_opt = (min1 == cost);
+        if (is_opt == want_optimal && cost < min_cost) { min_cost = cost; *m_x = d_mv_tab[ii][0]; *m_y = d_mv_tab[ii][1]; ii_best = ii; }
+        if (ii == 3 && min_cost != PCAMV_COST_MAX) break;
+    }
+    if (min_cost == PCAMV_COST_MAX) {
+        b_error_pos = 1; b_1_neighbor = 1;
+        *m_x = 0; *m_y = 0;
+        for (int k = 0; k < 4; k++) if (nb_cost[k] < min_cost) { min_cost = nb_cost[k]; *m_x = d_nb_tab[k][0]; *m_y = d_nb_tab[k][1]; }
+    } else b_1_neighbor = ii_best <= 3;
+    int cost_opt = min_cost > me->cost_rec ? min_cost - me->cost_rec : 1;
+    if (!b_1_neighbor) cost_opt = (int)(beta1 * (float)cost_opt);
+    else if (b_error_pos) cost_opt = (int)(beta2 * (float)cost_opt);
+    me->mv[0] = bmx; me->mv[1] = bmy;
+    update_cache(L, a);
+    return cost_opt;
+}
+
+/* carrier slots of a record in embedding order (encoder.c:1566-1647) */
+PCAMV_DEV int carrier_slots(int i_type, int i_partition, const uint8_t *sub, int used, int slots[16])
+{
+    int n = 0;
+    if (!used) return 0;
+    if (i_type == PCAMV_P_8x8) {
+        for (int i = 0; i < 4; i++)
+            switch (sub[i]) {
+            case PCAMV_D_L0_8x8: slots[n++] = i * 4; break;
+            case PCAMV_D_L0_4x8: slots[n++] = i * 4; slots[n++] = i * 4 + 1; break;
+            case PCAMV_D_L0_8x4: slots[n++] = i * 4; slots[n++] = i * 4 + 2; break;
+            default: for (int j = 0; j < 4; j++) slots[n++] = i * 4 + j; break;
+            }
+    } else if (i_type == PCAMV_P_L0) {
+        if (i_partition == PCAMV_D_16x16) slots[n++] = 0;
+        else if (i_partition == PCAMV_D_8x16) { slots[n++] = 0; slots[n++] = 4; }
+        else if (i_partition == PCAMV_D_16x8) { slots[n++] = 0; slots[n++] = 8; }
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------- phase A: search + decision */
+/* Analyse one macroblock (motion search, partition decision, early skip) and publish its final
+ * motion to the frame arrays its right/lower neighbours read.  Writes the record without the
+ * RCA fields; the search-time mvp of every carrier slot goes to mvp_aux for phase B. */
+PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    int b_skip = 0, b_try_pskip = 0, i_cost;
+    unsigned flags = F.inter;
+    for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
+    L->i_partition = PCAMV_D_16x16;
+    if (F.b_fast_pskip) {
+        if (F.subme >= 3) b_try_pskip = 1;
+        else if (L->type_left == PCAMV_P_SKIP || L->type_top == PCAMV_P_SKIP || L->type_topleft == PCAMV_P_SKIP || L->type_topright == PCAMV_P_SKIP)
+            b_skip = probe_pskip(F, L);
+    }
+    if (b_skip) { L->i_type = PCAMV_P_SKIP; L->i_partition = PCAMV_D_16x16; }
+    else if (!analyse_p16x16(F, L, a, b_try_pskip)) {
+        int i_type = PCAMV_P_L0, i_partition = PCAMV_D_16x16;
+        if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8(F, L, a);
+        i_cost = a->me16x16.cost;
+        if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost) {
+            if (flags & PCAMV_ANALYSE_PSUB8x8) {
+                i_type = PCAMV_P_8x8; i_partition = PCAMV_D_8x8; i_cost = a->cost8x8;
+                for (int i = 0; i < 4; i++) {
+                    analyse_sub8x8(F, L, a, i, PIX_4x4);
+                    if (a->cost4x4[i] < a->me8x8[i].cost) {
+                        int c8 = a->cost4x4[i];
+                        L->sub_part[i] = PCAMV_D_L0_4x4;
+                        analyse_sub8x8(F, L, a, i, PIX_8x4);
+                        if (a->cost8x4[i] < c8) { c8 = a->cost8x4[i]; L->sub_part[i] = PCAMV_D_L0_8x4; }
+                        analyse_sub8x8(F, L, a, i, PIX_4x8);
+                        if (a->cost4x8[i] < c8) { c8 = a->cost4x8[i]; L->sub_part[i] = PCAMV_D_L0_4x8; }
+                        i_cost += c8 - a->me8x8[i].cost;
+                    }
+                    cache_mv_p8x8(L, a, i);
+                }
+                a->cost8x8 = i_cost;
+            }
+        }
+        if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost + a->me8x8[1].cost_mv + a->me8x8[2].cost_mv) {
+            analyse_p16x8(F, L, a);
+            if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x8; }
+            analyse_p8x16(F, L, a);
+            if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
+        }
+        L->i_partition = i_partition;
+        if (i_partition == PCAMV_D_16x16) me_refine_qpel(F, L, &a->me16x16);
+        else if (i_partition == PCAMV_D_16x8) { me_refine_qpel(F, L, &a->me16x8[0]); me_refine_qpel(F, L, &a->me16x8[1]); }
+        else if (i_partition == PCAMV_D_8x16) { me_refine_qpel(F, L, &a->me8x16[0]); me_refine_qpel(F, L, &a->me8x16[1]); }
+        else
+            for (int i = 0; i < 4; i++)
+                switch (L->sub_part[i]) {
+                case PCAMV_D_L0_8x8: me_refine_qpel(F, L, &a->me8x8[i]); break;
+                case PCAMV_D_L0_8x4: me_refine_qpel(F, L, &a->me8x4[i][0]); me_refine_qpel(F, L, &a->me8x4[i][1]); break;
+                case PCAMV_D_L0_4x8: me_refine_qpel(F, L, &a->me4x8[i][0]); me_refine_qpel(F, L, &a->me4x8[i][1]); break;
+                default: for (int k = 0; k < 4; k++) me_refine_qpel(F, L, &a->me4x4[i][k]); break;
+                }
+        L->i_type = i_type;
+    }
+    update_cache(L, a);
+}
+
+/* the MEState that owns carrier slot s of the decided partitioning */
+PCAMV_DEV MEState *slot_me(MBLocal *L, Analysis *a, int slot)
+{
+    if (L->i_type == PCAMV_P_8x8) {
+        int i = slot >> 2, j = slot & 3;
+        switch (L->sub_part[i]) {
+        case PCAMV_D_L0_8x8: return &a->me8x8[i];
+        case PCAMV_D_L0_4x8: return &a->me4x8[i][j];
+        case PCAMV_D_L0_8x4: return &a->me8x4[i][j >> 1];
+        default: return &a->me4x4[i][j];
+        }
+    }
+    if (L->i_partition == PCAMV_D_16x16) return &a->me16x16;
+    if (L->i_partition == PCAMV_D_8x16) return &a->me8x16[slot >> 2];
+    return &a->me16x8[slot >> 3];
+}
+/* geometry of carrier slot s: pixel type and offset inside the MB */
+PCAMV_DEV void slot_geometry(int i_type, int i_partition, const uint8_t *sub, int slot, int *ip, int *xoff, int *yoff)
+{
+    if (i_type == PCAMV_P_8x8) {
+        int i = slot >> 2;
+        *xoff = 4 * blk_x_tab[slot]; *yoff = 4 * blk_y_tab[slot];
+        *ip = sub[i] == PCAMV_D_L0_8x8 ? PIX_8x8 : sub[i] == PCAMV_D_L0_4x8 ? PIX_4x8 : sub[i] == PCAMV_D_L0_8x4 ? PIX_8x4 : PIX_4x4;
+    } else if (i_partition == PCAMV_D_16x16) { *ip = PIX_16x16; *xoff = 0; *yoff = 0; }
+    else if (i_partition == PCAMV_D_8x16) { *ip = PIX_8x16; *xoff = slot ? 8 : 0; *yoff = 0; }
+    else { *ip = PIX_16x8; *xoff = 0; *yoff = slot ? 8 : 0; }
+}
+
+#endif

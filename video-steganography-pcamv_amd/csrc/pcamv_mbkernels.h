@@ -1,0 +1,106 @@
+/*
+ * pcamv_mbkernels.h -- per-macroblock bodies of the three analysis phases.
+ *
+ *   phase A  mbk_search : motion search + partition decision of one MB.  MB(x,y) needs the final
+ *                         motion of its left, top-left, top and top-right neighbours
+ *                         (common/macroblock.c:28-163, 422-439), so MBs on the anti-diagonal
+ *                         x + 2y = d are independent and diagonals run in order.
+ *   phase B  mbk_rca    : replacement-MV cost of ONE carrier MV (x264_ih_get_mv_cost,
+ *                         analyse.c:2391-2550): 1 + up to 12 whole-MB re-encodes, 9 SATDs each.
+ *                         Depends only on that MB's own decision -> embarrassingly parallel.
+ *   phase C  mbk_encode : the pass-1 reconstruction of the MB (encoder/macroblock.c:484).
+ */
+#ifndef PCAMV_MBKERNELS_H
+#define PCAMV_MBKERNELS_H
+#include "pcamv_logic.h"
+
+#ifdef PCAMV_HOST_EMU
+#define PCAMV_LANE0 1
+#else
+#define PCAMV_LANE0 (LANE() == 0)
+#endif
+
+PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
+{
+    mb_load(F, L, mb_x, mb_y);
+    analyse_mb_search(F, L, a);
+    const int xy = L->mb_xy;
+    int slots[16];
+    const int used = F.embed && L->i_type != PCAMV_P_SKIP;
+    const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, used, slots);
+    if (PCAMV_LANE0) {
+        pcamv_mb_t *r = &F.rec_mb[xy];
+        r->i_type = L->i_type; r->i_partition = L->i_partition; r->i_qp = F.qp;
+        for (int i = 0; i < 4; i++) r->i_sub_partition[i] = L->i_type == PCAMV_P_8x8 ? L->sub_part[i] : PCAMV_D_L0_8x8;
+        for (int i = 0; i < 16; i++) {
+            int i8 = scan8_of(i);
+            r->ref[i] = L->cref[i8]; r->mv[i][0] = L->cmv[i8][0]; r->mv[i][1] = L->cmv[i8][1];
+            r->mv_stego[i][0] = r->mv_stego[i][1] = 0; r->inter_stego_cost[i] = 0;
+        }
+        r->pskip_mv[0] = L->pskip_mv[0]; r->pskip_mv[1] = L->pskip_mv[1];
+        if (L->i_type != PCAMV_P_SKIP) { r->mvr16[0] = F.mvr[2 * xy]; r->mvr16[1] = F.mvr[2 * xy + 1]; }
+        else { r->mvr16[0] = r->mvr16[1] = 0; }
+        r->used = (uint8_t)used; r->pad[0] = r->pad[1] = r->pad[2] = 0;
+        for (int k = 0; k < n; k++) {
+            MEState *me = slot_me(L, a, slots[k]);
+            F.mvp_aux[(xy * 16 + slots[k]) * 2] = (int16_t)me->mvp[0];
+            F.mvp_aux[(xy * 16 + slots[k]) * 2 + 1] = (int16_t)me->mvp[1];
+        }
+        /* x264_macroblock_cache_save (common/macroblock.c:1254-1364): motion for the neighbours */
+        F.mb_type[xy] = (int8_t)L->i_type;
+        int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
+                F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
+            }
+        F.ref8[b8] = L->cref[scan8_of(0)]; F.ref8[b8 + 1] = L->cref[scan8_of(4)];
+        F.ref8[b8 + s8] = L->cref[scan8_of(8)]; F.ref8[b8 + s8 + 1] = L->cref[scan8_of(12)];
+    }
+}
+
+/* rebuild the decided partitioning (types, MVs, search-time mvp) from the record */
+PCAMV_DEV int analysis_from_record(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int slots[16])
+{
+    const pcamv_mb_t *r = &F.rec_mb[xy];
+    mb_load(F, L, xy % F.mb_w, xy / F.mb_w);
+    L->i_type = r->i_type; L->i_partition = r->i_partition;
+    for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
+    const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, L->i_type != PCAMV_P_SKIP, slots);
+    for (int k = 0; k < n; k++) {
+        int s = slots[k], ip, xo, yo;
+        MEState *me = slot_me(L, a, s);
+        slot_geometry(L->i_type, L->i_partition, L->sub_part, s, &ip, &xo, &yo);
+        me_setup(me, ip, xo, yo);
+        me->mv[0] = r->mv[s][0]; me->mv[1] = r->mv[s][1];
+        me->mvp[0] = F.mvp_aux[(xy * 16 + s) * 2]; me->mvp[1] = F.mvp_aux[(xy * 16 + s) * 2 + 1];
+    }
+    return n;
+}
+
+PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k)
+{
+    if (!F.rec_mb[xy].used) return;
+    int slots[16];
+    const int n = analysis_from_record(F, L, a, xy, slots);
+    if (k >= n) return;
+    MEState *me = slot_me(L, a, slots[k]);
+    int dx = 0, dy = 0;
+    const int bx = me->mv[0], by = me->mv[1];
+    const int cost = rca_mv_cost(F, L, a, me, &dx, &dy);
+    if (PCAMV_LANE0) {
+        pcamv_mb_t *r = &F.rec_mb[xy];
+        r->mv_stego[slots[k]][0] = (int16_t)(bx + dx); r->mv_stego[slots[k]][1] = (int16_t)(by + dy);
+        r->inter_stego_cost[slots[k]] = cost;
+    }
+}
+
+PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+{
+    int slots[16];
+    analysis_from_record(F, L, a, xy, slots);
+    update_cache(L, a);
+    mb_encode(F, L);
+    prim_store_rec(F, L);
+}
+#endif

@@ -1,0 +1,415 @@
+/*
+ * pcamv_prims_gpu.h -- lane-parallel pixel work for one wavefront (64 lanes) = one macroblock.
+ *
+ * Lane layout for block costs: a candidate block of w x h pixels is cut into its
+ * nblk = (w/4)*(h/4) 4x4 sub-blocks; lane = cand * nblk + blk, so one wavefront evaluates
+ * 64/nblk >= 4 candidates at once.  Each lane loads its 4x4 pixels (4 unaligned dword loads
+ * per plane, v_lerp_u8 for the quarter-pel average), computes SAD (v_sad_u8) or the 4x4
+ * Hadamard in registers, and the per-candidate total is a DPP butterfly over nblk lanes
+ * (quad_perm / row_half_mirror / row_mirror: no LDS traffic), read back with v_readlane.
+ * The reference frame is read straight from HBM/L2 with coalesced-enough dword loads; the
+ * source macroblock, prediction and reconstruction live in LDS (MBLocal).
+ *
+ * Arithmetic restated from the reference: common/pixel.c:40-65,187-253 (SAD/SATD),
+ * common/mc.c:194-277 (get_ref/mc_luma/mc_chroma), common/dct.c:122-232, common/quant.c:33-109,
+ * 203-239 (decimate), encoder/macroblock.c:71-85 (dct2x2dc).
+ */
+#ifndef PCAMV_PRIMS_GPU_H
+#define PCAMV_PRIMS_GPU_H
+#include "pcamv_common.h"
+
+#define LANE() ((int)(threadIdx.x & 63))
+
+__device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t lds4(const uint8_t *p) { return *(const uint32_t *)p; }
+__device__ __forceinline__ void sts4(uint8_t *p, uint32_t v) { *(uint32_t *)p = v; }
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+__device__ __forceinline__ int dpp_qp1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_qp2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_hmir(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_mir(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); }
+
+/* sum over aligned groups of g lanes (g = 1,2,4,8,16); every lane of a group gets the total */
+__device__ __forceinline__ int group_sum(int v, int g)
+{
+    if (g >= 2) v += dpp_qp1(v);
+    if (g >= 4) v += dpp_qp2(v);
+    if (g >= 8) v += dpp_hmir(v);
+    if (g >= 16) v += dpp_mir(v);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_all(int v)
+{
+    v = group_sum(v, 16);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+/* one row (4 pixels) of the quarter-pel reference sample, get_ref semantics */
+struct QpelPos { const uint8_t *a, *b; int two; };
+__device__ __forceinline__ QpelPos qpel_pos(const FrameDev &F, int px, int py, int mvx, int mvy)
+{
+    QpelPos q;
+    int qidx = ((mvy & 3) << 2) + (mvx & 3);
+    ptrdiff_t off = (ptrdiff_t)(py + (mvy >> 2)) * F.stride + px + (mvx >> 2);
+    q.a = F.luma[hpel_ref0_tab[qidx]] + off + ((mvy & 3) == 3) * F.stride;
+    q.two = (qidx & 5) != 0;
+    q.b = F.luma[hpel_ref1_tab[qidx]] + off + ((mvx & 3) == 3);
+    return q;
+}
+__device__ __forceinline__ uint32_t qpel_row(const QpelPos &q, const FrameDev &F, int r)
+{
+    uint32_t a = ld4u(q.a + (ptrdiff_t)r * F.stride);
+    if (q.two) a = avg4(a, ld4u(q.b + (ptrdiff_t)r * F.stride));
+    return a;
+}
+
+__device__ __forceinline__ int hadamard4x4_abs(const uint32_t e[4], const uint32_t r[4])
+{
+    int t[4][4], s = 0;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        int d0 = (int)(e[y] & 255) - (int)(r[y] & 255), d1 = (int)((e[y] >> 8) & 255) - (int)((r[y] >> 8) & 255);
+        int d2 = (int)((e[y] >> 16) & 255) - (int)((r[y] >> 16) & 255), d3 = (int)(e[y] >> 24) - (int)(r[y] >> 24);
+        int s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
+        t[y][0] = s01 + s23; t[y][1] = d01 + d23; t[y][2] = s01 - s23; t[y][3] = d01 - d23;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        int s01 = t[0][x] + t[1][x], d01 = t[0][x] - t[1][x], s23 = t[2][x] + t[3][x], d23 = t[2][x] - t[3][x];
+        s += iabs(s01 + s23) + iabs(d01 + d23) + iabs(s01 - s23) + iabs(d01 - d23);
+    }
+    return s;
+}
+
+/* n <= 4 quarter-pel candidates of block (ip at xoff,yoff) against source rows in enc (LDS, stride 16) */
+__device__ __forceinline__ void prim_cost_luma_xn(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff,
+                                                  const int *mx, const int *my, int n, int satd, int *out)
+{
+    const int w4 = pix_w_tab[ip] >> 2, nblk = w4 * (pix_h_tab[ip] >> 2);
+    const int lane = LANE();
+    const int cand = lane / nblk, blk = lane - cand * nblk;
+    const int bx = blk % w4, by = blk / w4;
+    const bool act = cand < n && cand < 4;
+    int v = 0;
+    if (act) {
+        int mvx = cand == 0 ? mx[0] : cand == 1 ? mx[1] : cand == 2 ? mx[2] : mx[3];
+        int mvy = cand == 0 ? my[0] : cand == 1 ? my[1] : cand == 2 ? my[2] : my[3];
+        int px = xoff + 4 * bx, py = yoff + 4 * by;
+        QpelPos q = qpel_pos(F, L->mb_x * 16 + px, L->mb_y * 16 + py, mvx, mvy);
+        uint32_t e[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { r[k] = qpel_row(q, F, k); e[k] = lds4(enc + (py + k) * 16 + px); }
+        if (satd) v = hadamard4x4_abs(e, r);
+        else {
+            uint32_t s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(e[k], r[k], s);
+            v = (int)s;
+        }
+    }
+    if (satd) {
+        if (w4 >= 2) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }   /* 8x4 units: two 4x4 sums halved together */
+        else v >>= 1;
+    }
+    v = group_sum(v, nblk);
+    for (int c = 0; c < n; c++) out[c] = __builtin_amdgcn_readlane(v, c * nblk);
+}
+__device__ __forceinline__ int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
+{
+    int o[1], ax[1] = {mx}, ay[1] = {my};
+    prim_cost_luma_xn(F, L, enc, ip, xoff, yoff, ax, ay, 1, satd, o);
+    return o[0];
+}
+__device__ __forceinline__ void prim_sad_fpel_xn(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int *out)
+{
+    int qx[4], qy[4];
+    for (int k = 0; k < n; k++) { qx[k] = mx[k] << 2; qy[k] = my[k] << 2; }
+    prim_cost_luma_xn(F, L, L->fenc, ip, xoff, yoff, qx, qy, n, 0, out);
+}
+
+/* 4 chroma pixels of mc_chroma (mc.c:246-277) at chroma-plane position (cx,cy) */
+__device__ __forceinline__ uint32_t chroma_row4(const FrameDev &F, int plane, int cx, int cy, int mvx, int mvy)
+{
+    int dx = mvx & 7, dy = mvy & 7;
+    int cA = (8 - dx) * (8 - dy), cB = dx * (8 - dy), cC = (8 - dx) * dy, cD = dx * dy;
+    const uint8_t *s = F.chroma[plane] + (ptrdiff_t)(cy + (mvy >> 3)) * F.cstride + cx + (mvx >> 3);
+    uint32_t a0 = ld4u(s), a1 = s[4], b0 = ld4u(s + F.cstride), b1 = s[F.cstride + 4];
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int p00 = (a0 >> (8 * i)) & 255, p01 = i < 3 ? (a0 >> (8 * i + 8)) & 255 : a1;
+        int p10 = (b0 >> (8 * i)) & 255, p11 = i < 3 ? (b0 >> (8 * i + 8)) & 255 : b1;
+        o |= (uint32_t)((cA * p00 + cB * p01 + cC * p10 + cD * p11 + 32) >> 6) << (8 * i);
+    }
+    return o;
+}
+/* chroma cost of both planes for the block co-located with luma block (ip,xoff,yoff): lanes 0..nb-1 = U, nb..2nb-1 = V */
+__device__ __forceinline__ void prim_cost_chroma_uv(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff,
+                                                    int mx, int my, int satd, int *cu, int *cv)
+{
+    const int cw4 = pix_w_tab[ip] >> 3, nb = cw4 * (pix_h_tab[ip] >> 3);     /* chroma 4x4 blocks: 4,2,2,1 */
+    const int lane = LANE();
+    const int plane = lane / nb, blk = lane - plane * nb;
+    const int bx = blk % cw4, by = blk / cw4;
+    int v = 0;
+    if (plane < 2) {
+        int px = (xoff >> 1) + 4 * bx, py = (yoff >> 1) + 4 * by;
+        uint32_t e[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[k] = chroma_row4(F, plane, L->mb_x * 8 + px, L->mb_y * 8 + py + k, mx, my);
+            e[k] = lds4(enc + 256 + (py + k) * 16 + plane * 8 + px);
+        }
+        if (satd) v = hadamard4x4_abs(e, r);
+        else { uint32_t s = 0; for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(e[k], r[k], s); v = (int)s; }
+    }
+    if (satd) {
+        if (cw4 >= 2) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }
+        else v >>= 1;
+    }
+    v = group_sum(v, nb);
+    *cu = __builtin_amdgcn_readlane(v, 0);
+    *cv = __builtin_amdgcn_readlane(v, nb);
+}
+__device__ __forceinline__ int prim_cost_chroma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int plane, int mx, int my, int satd)
+{
+    int cu, cv;
+    prim_cost_chroma_uv(F, L, enc, ip, xoff, yoff, mx, my, satd, &cu, &cv);
+    return plane ? cv : cu;
+}
+/* analyse.c:1535-1567: chroma cost of one 8x8 split below 8x8; mv4[k] = MV of luma 4x4 k (raster in the 8x8) */
+__device__ __forceinline__ int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
+{
+    const int lane = LANE();
+    int v = 0;
+    if (lane < 2) {
+        int ox = 4 * (i8 & 1), oy = 2 * (i8 & 2);
+        uint32_t e[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; hlf++) {
+                int q = (k >> 1) * 2 + hlf;
+                uint32_t t = chroma_row4(F, lane, L->mb_x * 8 + ox + 2 * hlf, L->mb_y * 8 + oy + k, mv4x[q], mv4y[q]);
+                o |= (t & 0xFFFFu) << (16 * hlf);
+            }
+            r[k] = o;
+            e[k] = lds4(L->fenc + 256 + (oy + k) * 16 + lane * 8 + ox);
+        }
+        if (satd) v = hadamard4x4_abs(e, r) >> 1;
+        else { uint32_t s = 0; for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(e[k], r[k], s); v = (int)s; }
+    }
+    v = group_sum(v, 2);
+    return __builtin_amdgcn_readlane(v, 0);
+}
+
+__device__ __forceinline__ void prim_load_fenc(const FrameDev &F, MBLocal *L)
+{
+    const int lane = LANE();
+    { int row = lane >> 2, c4 = lane & 3;
+      sts4(L->fenc + row * 16 + c4 * 4, *(const uint32_t *)(F.fenc[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4)); }
+    if (lane < 32) {
+        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        sts4(L->fenc + 256 + row * 16 + plane * 8 + c4 * 4,
+             *(const uint32_t *)(F.fenc[1 + plane] + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4));
+    }
+}
+
+/* inter prediction of the whole MB from the per-4x4 MVs in L->cmv (x264_mb_mc, common/macroblock.c:483-508,626-690) */
+__device__ __forceinline__ void predict_luma_lane(const FrameDev &F, MBLocal *L, int lane, int mvx, int mvy)
+{
+    int row = lane >> 2, c4 = lane & 3;
+    QpelPos q = qpel_pos(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
+    sts4(L->pred + row * 16 + 4 * c4, qpel_row(q, F, 0));
+}
+__device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
+{
+    const int lane = LANE();
+    { int row = lane >> 2, c4 = lane & 3, i8 = SCAN8_0 + c4 + 8 * (row >> 2);
+      int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+      predict_luma_lane(F, L, lane, mvx, mvy); }
+    if (lane < 32) {
+        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        uint32_t o = 0;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            int i8 = SCAN8_0 + (2 * c4 + hlf) + 8 * (row >> 1);
+            int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+            uint32_t t = chroma_row4(F, plane, L->mb_x * 8 + 4 * c4 + 2 * hlf, L->mb_y * 8 + row, mvx, mvy);
+            o |= (t & 0xFFFFu) << (16 * hlf);
+        }
+        sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, o);
+    }
+}
+/* which: 0 luma only, 1 luma+chroma, 2 chroma only; (mvx,mvy) already clipped */
+__device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L, int mvx, int mvy, int which)
+{
+    const int lane = LANE();
+    if (which != 2) predict_luma_lane(F, L, lane, mvx, mvy);
+    if (which != 0 && lane < 32) {
+        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, chroma_row4(F, plane, L->mb_x * 8 + 4 * c4, L->mb_y * 8 + row, mvx, mvy));
+    }
+}
+
+/* forward 4x4 transform + quantisation + scan score + dequantisation, one 4x4 block per lane:
+ * lanes 0..15 luma blocks (x264 block order), 16..19 U, 20..23 V. */
+__device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int do_luma, int do_chroma)
+{
+    const int lane = LANE();
+    const bool is_l = lane < 16 && do_luma, is_c = lane >= 16 && lane < 24 && do_chroma;
+    int16_t d[16];
+    if (is_l || is_c) {
+        int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+        int px = is_l ? 4 * blk_x_tab[lane] : ch * 8 + (ci & 1) * 4;
+        int py = is_l ? 4 * blk_y_tab[lane] : 16 + (ci >> 1) * 4;
+        int t[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(L->pred + (py + y) * 16 + px);
+            int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
+            int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
+            int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
+            t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+            d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
+        }
+        if (is_c) { L->red[lane] = d[0]; d[0] = 0; }
+        const int cat = is_l ? 0 : 1, qp = is_l ? F.qp : F.chroma_qp;
+        int nz = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            int cls = (i & 1) + ((i >> 2) & 1), mf = F.q_mf[cat][cls], bias = F.q_bias[cat][cls], c = d[i];
+            c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+            d[i] = (int16_t)c; nz |= c;
+        }
+        nz = nz != 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) L->coef[lane][i] = d[i];
+        /* decimate score on the zigzag scan (16 coefficients for luma, the 15 AC ones for chroma);
+         * scanned out of LDS: a register array must not be indexed dynamically */
+        int score = 0;
+        if (nz) {
+            const int16_t *q = L->coef[lane];
+            int idx = 15, lo = is_l ? 0 : 1;
+            while (idx >= lo && q[zz4_tab[idx]] == 0) idx--;
+            while (idx >= lo) {
+                int c = q[zz4_tab[idx--]];
+                if ((unsigned)(c + 1) > 2) { score = 9; break; }
+                int run = 0;
+                while (idx >= lo && q[zz4_tab[idx]] == 0) { idx--; run++; }
+                score += decimate_tab4[run];
+            }
+            const int qbits = qp / 6 - 4;
+            const int *dq = is_l ? F.dq_mf : F.dq_mf_c;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int cls = (i & 1) + ((i >> 2) & 1);
+                L->coef[lane][i] = qbits >= 0 ? (int16_t)((d[i] * dq[cls]) << qbits) : (int16_t)((d[i] * dq[cls] + (1 << (-qbits - 1))) >> (-qbits));
+            }
+        }
+        L->blk_nz[lane] = nz; L->blk_score[lane] = score;
+    }
+    if (is_c && ((lane - 16) & 3) == 0) {
+        /* dct2x2dc over the four raw DCs of this plane */
+        int ch = (lane - 16) >> 2;
+        int b0 = L->red[lane], b1 = L->red[lane + 1], b2 = L->red[lane + 2], b3 = L->red[lane + 3];
+        int d0 = b0 + b1, d1 = b2 + b3, d2 = b0 - b1, d3 = b2 - b3;
+        L->cdc[ch][0] = (int16_t)(d0 + d1); L->cdc[ch][1] = (int16_t)(d0 - d1); L->cdc[ch][2] = (int16_t)(d2 + d3); L->cdc[ch][3] = (int16_t)(d2 - d3);
+    }
+}
+
+__device__ __forceinline__ void idct4x4_add(uint8_t *dst, const int16_t *c)   /* dst stride 16 */
+{
+    int16_t t[4][4], r[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int s02 = c[0 * 4 + i] + c[2 * 4 + i], d02 = c[0 * 4 + i] - c[2 * 4 + i];
+        int s13 = c[1 * 4 + i] + (c[3 * 4 + i] >> 1), d13 = (c[1 * 4 + i] >> 1) - c[3 * 4 + i];
+        t[i][0] = (int16_t)(s02 + s13); t[i][1] = (int16_t)(d02 + d13); t[i][2] = (int16_t)(d02 - d13); t[i][3] = (int16_t)(s02 - s13);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int s02 = t[0][i] + t[2][i], d02 = t[0][i] - t[2][i];
+        int s13 = t[1][i] + (t[3][i] >> 1), d13 = (t[1][i] >> 1) - t[3][i];
+        r[0][i] = (int16_t)((s02 + s13 + 32) >> 6); r[1][i] = (int16_t)((d02 + d13 + 32) >> 6);
+        r[2][i] = (int16_t)((d02 - d13 + 32) >> 6); r[3][i] = (int16_t)((s02 - s13 + 32) >> 6);
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t p = lds4(dst + y * 16), o = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((p >> (8 * x)) & 255) + r[y][x], 0, 255) << (8 * x);
+        sts4(dst + y * 16, o);
+    }
+}
+__device__ __forceinline__ void prim_add_idct(const FrameDev &F, MBLocal *L, unsigned keep, int cm0, int cm1)
+{
+    const int lane = LANE();
+    if (lane < 16) {
+        if (((keep >> lane) & 1) && L->blk_nz[lane]) {
+            int16_t c[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) c[i] = L->coef[lane][i];
+            idct4x4_add(L->pred + 4 * blk_y_tab[lane] * 16 + 4 * blk_x_tab[lane], c);
+        }
+    } else if (lane < 24) {
+        int ch = (lane - 16) >> 2, ci = (lane - 16) & 3, mode = ch ? cm1 : cm0;
+        uint8_t *dst = L->pred + 256 + (ci >> 1) * 4 * 16 + ch * 8 + (ci & 1) * 4;
+        if (mode == 2) {
+            int16_t c[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) c[i] = L->coef[lane][i];
+            idct4x4_add(dst, c);
+        } else if (mode == 1) {
+            int v = ((int)(int16_t)L->cdc[ch][ci] + 32) >> 6;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t p = lds4(dst + y * 16), o = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((p >> (8 * x)) & 255) + v, 0, 255) << (8 * x);
+                sts4(dst + y * 16, o);
+            }
+        }
+    }
+    (void)F;
+}
+__device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
+{
+    const int lane = LANE();
+    int v = 0;
+    if (lane < 16) {
+        int row = lane >> 1, c4 = lane & 1;
+        uint32_t e = lds4(L->fenc + 256 + row * 16 + ch * 8 + c4 * 4), p = lds4(L->pred + 256 + row * 16 + ch * 8 + c4 * 4);
+#pragma unroll
+        for (int x = 0; x < 4; x++) { int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += dd * dd; }
+    }
+    v = group_sum(v, 16);
+    (void)F;
+    return __builtin_amdgcn_readlane(v, 0);
+}
+__device__ __forceinline__ void prim_copy_pred_to_rec(MBLocal *L)
+{
+    const int lane = LANE();
+    ((uint32_t *)L->recb)[lane] = ((const uint32_t *)L->pred)[lane];
+    if (lane < 32) ((uint32_t *)L->recb)[64 + lane] = ((const uint32_t *)L->pred)[64 + lane];
+}
+__device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L)
+{
+    const int lane = LANE();
+    { int row = lane >> 2, c4 = lane & 3;
+      *(uint32_t *)(F.rec[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4) = lds4(L->pred + row * 16 + c4 * 4); }
+    if (lane < 32) {
+        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        *(uint32_t *)(F.rec[1 + plane] + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4) = lds4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4);
+    }
+}
+__device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, int mvx, int mvy)
+{
+    if (LANE() == 0) { F.mvr[2 * L->mb_xy] = (int16_t)mvx; F.mvr[2 * L->mb_xy + 1] = (int16_t)mvy; }
+}
+#endif

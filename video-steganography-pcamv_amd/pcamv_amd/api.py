@@ -1,0 +1,275 @@
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_CSRC = os.path.join(_PKG, "csrc")
+
+ME_NAMES = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}      # x264_motion_est_names, x264.h:113
+P_L0, P_8x8, P_SKIP = 4, 5, 6
+PSUB16x16, PSUB8x8 = 0x10, 0x20
+
+
+class PcamvError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """pcamv_params_t: the x264_param_t fields this path reads (same names)."""
+    _fields_ = [("i_width", C.c_int32), ("i_height", C.c_int32), ("i_me_method", C.c_int32),
+                ("i_me_range", C.c_int32), ("i_subpel_refine", C.c_int32), ("i_mv_range", C.c_int32),
+                ("b_chroma_me", C.c_int32), ("b_fast_pskip", C.c_int32), ("b_dct_decimate", C.c_int32),
+                ("b_cabac", C.c_int32), ("inter", C.c_uint32), ("i_chroma_qp_offset", C.c_int32),
+                ("i_luma_deadzone", C.c_int32 * 2), ("i_tscale", C.c_int32)]
+
+
+class _Embed(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("stc_ok", C.c_int32), ("num_flip", C.c_int32),
+                ("cover", C.c_void_p), ("rho", C.c_void_p), ("message", C.c_void_p),
+                ("stego", C.c_void_p), ("flip", C.c_void_p)]
+
+
+MB_DTYPE = np.dtype([("i_type", "<i4"), ("i_partition", "<i4"), ("i_qp", "<i4"),
+                     ("i_sub_partition", "u1", (4,)), ("ref", "i1", (16,)),
+                     ("mv", "<i2", (16, 2)), ("mv_stego", "<i2", (16, 2)),
+                     ("inter_stego_cost", "<i4", (16,)), ("pskip_mv", "<i2", (2,)),
+                     ("mvr16", "<i2", (2,)), ("used", "u1"), ("pad", "u1", (3,))])
+
+_LEVELS = [(10, 1485, 99, 148500, 64), (11, 3000, 396, 337500, 128), (12, 6000, 396, 891000, 128),
+           (13, 11880, 396, 891000, 128), (20, 11880, 396, 891000, 128), (21, 19800, 792, 1782000, 256),
+           (22, 20250, 1620, 3037500, 256), (30, 40500, 1620, 3037500, 256), (31, 108000, 3600, 6750000, 512),
+           (32, 216000, 5120, 7680000, 512), (40, 245760, 8192, 12288000, 512), (41, 245760, 8192, 12288000, 512),
+           (42, 522240, 8704, 13056000, 512), (50, 589824, 22080, 41400000, 512), (51, 983040, 36864, 69120000, 512)]
+
+
+def level_mv_range(width, height, fps=25):
+    """Vertical MV range of the lowest H.264 level admitting the stream with one reference frame
+    (what x264_validate_levels + encoder.c:540-559 leave in analyse.i_mv_range)."""
+    mbs = (width // 16) * (height // 16)
+    for _, mbps, fs, dpb, mvr in _LEVELS:
+        if fs >= mbs and mbps >= mbs * fps and dpb >= 384 * mbs:
+            return mvr
+    return 512
+
+
+def param_default(width, height):
+    """x264_param_default (common/common.c:39-146) for the fields of this path."""
+    p = Params()
+    p.i_width, p.i_height = width, height
+    p.i_me_method, p.i_me_range, p.i_subpel_refine = ME_NAMES["hex"], 16, 5
+    p.i_mv_range = level_mv_range(width, height)
+    p.b_chroma_me = p.b_fast_pskip = p.b_dct_decimate = p.b_cabac = 1
+    p.inter = PSUB16x16
+    p.i_chroma_qp_offset = 0
+    p.i_luma_deadzone[0], p.i_luma_deadzone[1] = 21, 11
+    p.i_tscale = 256
+    return p
+
+
+def param_parse(p, name, value):
+    """x264_param_parse (common/common.c:229-560) for the option names of this path."""
+    name = name.lstrip("-").replace("_", "-")
+    if name == "me":
+        if value not in ME_NAMES:
+            raise PcamvError(f"invalid value for me: {value}")
+        p.i_me_method = ME_NAMES[value]
+    elif name in ("merange", "me-range"):
+        p.i_me_range = int(value)
+    elif name in ("subme", "subq"):
+        p.i_subpel_refine = int(value)
+    elif name == "mvrange":
+        p.i_mv_range = int(value)
+    elif name in ("partitions", "analyse"):
+        v = 0
+        toks = [t.strip() for t in str(value).split(",")]
+        if "none" in toks:
+            v = 0
+        if "all" in toks or "p8x8" in toks:
+            v |= PSUB16x16
+        if "all" in toks or "p4x4" in toks:
+            v |= PSUB8x8
+        if not (v & PSUB16x16):
+            v &= ~PSUB8x8
+        p.inter = v
+    elif name == "no-chroma-me":
+        p.b_chroma_me = 0
+    elif name == "no-fast-pskip":
+        p.b_fast_pskip = 0
+    elif name == "no-dct-decimate":
+        p.b_dct_decimate = 0
+    elif name == "no-cabac":
+        p.b_cabac = 0
+    elif name == "chroma-qp-offset":
+        p.i_chroma_qp_offset = int(value)
+    else:
+        raise PcamvError(f"unknown option: {name}")
+    return p
+
+
+def lib_path():
+    return os.path.join(_PKG, "libpcamv_gpu.so")
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip into the in-tree libpcamv_gpu.so."""
+    out = lib_path()
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "pcamv_gpu.h"))
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+           "-Wno-unused-value", "-Wno-unused-result", "-o", out, os.path.join(_CSRC, "pcamv_gpu.hip")]
+    subprocess.check_call(cmd)
+    return out
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise PcamvError(f"{path} is missing: run __graft_entry__.build() (hipcc). There is no CPU fallback.")
+        _lib = C.CDLL(path)
+        _lib.pcamv_gpu_last_error.restype = C.c_char_p
+        _lib.pcamv_gpu_last_error.argtypes = [C.c_void_p]
+        _lib.pcamv_gpu_close.restype = None
+        _lib.pcamv_gpu_close.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def stc_extract(stego, m, height=10):
+    stego = np.ascontiguousarray(stego, np.uint8)
+    msg = np.zeros(m, np.uint8)
+    rc = load_library().pcamv_gpu_stc_extract(_p(stego), len(stego), m, height, _p(msg))
+    if rc:
+        raise PcamvError(f"pcamv_gpu_stc_extract failed: {rc}")
+    return msg
+
+
+class Encoder:
+    """One analysis context = one x264_t's worth of P-frame analysis state on one GPU."""
+
+    def __init__(self, params, device=0):
+        self.lib = load_library()
+        self.p = params
+        self.w, self.h = params.i_width, params.i_height
+        self.n_mb = (self.w // 16) * (self.h // 16)
+        ctx = C.c_void_p()
+        rc = self.lib.pcamv_gpu_open(C.byref(params), device, C.byref(ctx))
+        if rc:
+            names = {-1: "invalid parameter", -2: "no HIP device (there is no CPU fallback)", -3: "out of memory",
+                     -4: "HIP error", -5: "unsupported (subme>=6 / esa / tesa are not on the GPU path yet)"}
+            raise PcamvError(f"pcamv_gpu_open failed: {names.get(rc, rc)}")
+        self.ctx = ctx
+
+    def _chk(self, rc, what):
+        if rc:
+            raise PcamvError(f"{what} failed ({rc}): {self.lib.pcamv_gpu_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.pcamv_gpu_close(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _planes(self, y, u, v):
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in (y, u, v)]
+        ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in arrs])
+        strides = (C.c_int * 3)(*[a.shape[1] for a in arrs])
+        return arrs, ptrs, strides
+
+    def upload_fenc(self, y, u, v):
+        keep, ptrs, strides = self._planes(y, u, v)
+        self._chk(self.lib.pcamv_gpu_upload_fenc(self.ctx, ptrs, strides), "upload_fenc")
+
+    def set_ref(self, y, u, v, prev_mv=None, prev_ref=None):
+        keep, ptrs, strides = self._planes(y, u, v)
+        if prev_mv is not None:
+            prev_mv = np.ascontiguousarray(prev_mv, np.int16)
+            prev_ref = np.ascontiguousarray(prev_ref, np.int8)
+        self._chk(self.lib.pcamv_gpu_set_ref(self.ctx, ptrs, strides, _p(prev_mv), _p(prev_ref)), "set_ref")
+
+    def ref_planes(self):
+        stride = (self.w + 64 + 15) & ~15
+        out = np.zeros((4, self.h + 64, stride), np.uint8)
+        st, ln = C.c_int(), C.c_int()
+        self._chk(self.lib.pcamv_gpu_get_ref_planes(self.ctx, _p(out), C.byref(st), C.byref(ln)), "get_ref_planes")
+        assert st.value == stride and ln.value == self.h + 64
+        return out
+
+    def analyse_pframe(self, qp, embed=1, want_recon=True):
+        mbs = np.zeros(self.n_mb, MB_DTYPE)
+        rec = [np.zeros((self.h, self.w), np.uint8), np.zeros((self.h // 2, self.w // 2), np.uint8),
+               np.zeros((self.h // 2, self.w // 2), np.uint8)]
+        ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in rec]) if want_recon else None
+        self._chk(self.lib.pcamv_gpu_analyse_pframe(self.ctx, qp, embed, _p(mbs), ptrs), "analyse_pframe")
+        return mbs, rec
+
+    def _embed_bufs(self):
+        cap = 16 * self.n_mb
+        arr = dict(cover=np.zeros(cap, np.uint8), rho=np.zeros(cap, np.float32), message=np.zeros(cap, np.uint8),
+                   stego=np.zeros(cap, np.uint8), flip=np.zeros(cap, np.int8))
+        e = _Embed(0, 0, 0, 0, *[arr[k].ctypes.data for k in ("cover", "rho", "message", "stego", "flip")])
+        return arr, e
+
+    @staticmethod
+    def _embed_out(arr, e):
+        out = {k: v[:e.n].copy() for k, v in arr.items()}
+        out["message"] = arr["message"][:e.m].copy()
+        out.update(n=e.n, m=e.m, stc_ok=e.stc_ok, num_flip=e.num_flip)
+        return out
+
+    def embed_pframe(self, emrate, message=None):
+        arr, e = self._embed_bufs()
+        if message is not None:
+            message = np.ascontiguousarray(message, np.uint8)
+        self._chk(self.lib.pcamv_gpu_embed_pframe(self.ctx, C.c_float(emrate), _p(message),
+                                                  0 if message is None else len(message), C.byref(e)), "embed_pframe")
+        return self._embed_out(arr, e)
+
+    def final_mvs(self, mbs):
+        out = mbs.copy()
+        self._chk(self.lib.pcamv_gpu_final_mvs(self.ctx, _p(out)), "final_mvs")
+        return out
+
+    def block_costs(self, qp, requests):
+        req = np.ascontiguousarray(requests, np.int32).reshape(-1, 8)
+        out = np.zeros((len(req), 3), np.int32)
+        self._chk(self.lib.pcamv_gpu_block_costs(self.ctx, qp, len(req), _p(req), _p(out)), "block_costs")
+        return out
+
+    # device-resident path (bench.py): raw device pointers as integers
+    def set_ref_device(self, y, u, v, prev_mv=0, prev_ref=0):
+        self._chk(self.lib.pcamv_gpu_set_ref_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v),
+                                                    C.c_void_p(prev_mv or None), C.c_void_p(prev_ref or None)), "set_ref_device")
+
+    def set_fenc_device(self, y, u, v):
+        self._chk(self.lib.pcamv_gpu_set_fenc_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v)), "set_fenc_device")
+
+    def step_device(self, qp, emrate, stream=0):
+        self._chk(self.lib.pcamv_gpu_step_device(self.ctx, qp, C.c_float(emrate), C.c_void_p(stream or None)), "step_device")
+
+    def fetch_results(self, want_embed=True):
+        mbs = np.zeros(self.n_mb, MB_DTYPE)
+        arr, e = self._embed_bufs()
+        self._chk(self.lib.pcamv_gpu_fetch_results(self.ctx, _p(mbs), C.byref(e) if want_embed else None), "fetch_results")
+        return mbs, (self._embed_out(arr, e) if want_embed else None)
+
+    def kernel_time(self, kernel="k_search_diag", reset=True):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(self.lib.pcamv_gpu_kernel_time(self.ctx, kernel.encode(), C.byref(ms), C.byref(n), int(reset)), "kernel_time")
+        return ms.value, n.value
