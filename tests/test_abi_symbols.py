@@ -49,4 +49,4 @@ def test_param_parse_mirrors_reference_option_names():
     assert (p.i_me_method, p.i_subpel_refine, p.inter) == (2, 4, 0x30)
     with pytest.raises(pcamv_amd.PcamvError):
         pcamv_amd.param_parse(p, "me", "bogus")
-    assert pcamv_amd.level_mv_range(352, 288) == 128 and pcamv_amd.level_mv_range(176, 144) == 64
+    assert pcamv_amd.level_mv_range(352, 288) == 128 and pcamv_amd.level_mv_range(176, 144) == 128
