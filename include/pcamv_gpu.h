@@ -151,6 +151,9 @@ int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int matrixheight, 
  * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */
 int pcamv_gpu_set_ref_device(pcamv_ctx_t *ctx, const void *y, const void *u, const void *v,
                              const void *prev_mv, const void *prev_ref);
+/* pass as prev_mv and prev_ref to chain frames on the device: the temporal candidates then come
+ * from the motion field the context's previous step produced (kept in a ping-pong buffer) */
+#define PCAMV_PREV_FIELD_INTERNAL ((const void *)(uintptr_t)1)
 int pcamv_gpu_set_fenc_device(pcamv_ctx_t *ctx, const void *y, const void *u, const void *v);
 /* One full step on resident inputs: plane production + analysis + RCA + embedding; results
  * stay on the device until pcamv_gpu_fetch_results. stream = hipStream_t as void*. */
@@ -165,6 +168,11 @@ int pcamv_gpu_kernel_time(pcamv_ctx_t *ctx, const char *kernel, double *avg_ms, 
  * satd}, each answered with {luma cost, U cost, V cost} of the uploaded fenc block against the
  * current reference at that MV (no MV-bit cost added). */
 int pcamv_gpu_block_costs(pcamv_ctx_t *ctx, int qp, int n, const int32_t *req, int32_t *out);
+
+/* Diagnostics: record every block-cost evaluation {ip,xoff,yoff,mvx,mvy,flags,cost,cost2} made for
+ * macroblock mb by the next analyse call (mb < 0: off); out holds 1 + 8*4000 int32, out[0] = count. */
+int pcamv_gpu_trace_mb(pcamv_ctx_t *ctx, int mb);
+int pcamv_gpu_trace_fetch(pcamv_ctx_t *ctx, int32_t *out);
 
 int pcamv_gpu_abi_version(void);
 

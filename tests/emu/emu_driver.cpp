@@ -15,12 +15,12 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
                                   const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                                   uint8_t *luma4, uint8_t *cu, uint8_t *cv,
                                   const int16_t *prev_mv, const int8_t *prev_ref,
-                                  pcamv_mb_t *out, uint8_t *ry, uint8_t *ru, uint8_t *rv, int diag_order)
+                                  pcamv_mb_t *out, uint8_t *ry, uint8_t *ru, uint8_t *rv, int diag_order, int *trace, int trace_mb)
 {
     FrameDev F = {};
     pcamv_frame_set_params(&F, p);
     pcamv_frame_set_qp(&F, p, qp);
-    F.embed = embed;
+    F.embed = embed; F.trace = trace; F.trace_mb = trace_mb;
     F.fenc[0] = fy; F.fenc[1] = fu; F.fenc[2] = fv;
     size_t lsz = (size_t)F.stride * F.lines;
     for (int k = 0; k < 4; k++) F.luma[k] = luma4 + k * lsz + (size_t)F.stride * PCAMV_PAD + PCAMV_PAD;

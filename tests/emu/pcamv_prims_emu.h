@@ -44,16 +44,22 @@ static inline int emu_cmp(int w, int h, const uint8_t *a, int sa, const uint8_t 
         s += (emu_had4(a + y * sa + x, sa, b + y * sb + x, sb) + emu_had4(a + y * sa + x + 4, sa, b + y * sb + x + 4, sb)) >> 1;
     return s;
 }
-static inline int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
+static inline int prim_cost_luma_nolog(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
 {
     uint8_t tmp[32 * 20]; int st, w = pix_w_tab[ip], h = pix_h_tab[ip];
     const uint8_t *r = emu_qpel(F, tmp, &st, L->mb_x * 16 + xoff, L->mb_y * 16 + yoff, mx, my, w, h);
     return emu_cmp(w, h, enc + yoff * 16 + xoff, 16, r, st, satd);
 }
 static inline void prim_cost_luma_xn(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int satd, int *out)
-{ for (int k = 0; k < n; k++) out[k] = prim_cost_luma(F, L, enc, ip, xoff, yoff, mx[k], my[k], satd); }
+{
+    for (int k = 0; k < n; k++) out[k] = prim_cost_luma_nolog(F, L, enc, ip, xoff, yoff, mx[k], my[k], satd);
+    if (F.trace && L->mb_xy == F.trace_mb)
+        for (int c = 0; c < n; c++) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx[c]; t[4] = my[c]; t[5] = satd | (enc == L->recb ? 2 : 0); t[6] = out[c]; t[7] = 0; F.trace[0] = k + 1; } }
+}
+static inline int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
+{ int o[4] = {0, 0, 0, 0}, ax[4] = {mx, mx, mx, mx}, ay[4] = {my, my, my, my}; prim_cost_luma_xn(F, L, enc, ip, xoff, yoff, ax, ay, 1, satd, o); return o[0]; }
 static inline void prim_sad_fpel_xn(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int *out)
-{ for (int k = 0; k < n; k++) out[k] = prim_cost_luma(F, L, L->fenc, ip, xoff, yoff, mx[k] << 2, my[k] << 2, 0); }
+{ int qx[4], qy[4]; for (int k = 0; k < 4; k++) { qx[k] = mx[k] * 4; qy[k] = my[k] * 4; } prim_cost_luma_xn(F, L, L->fenc, ip, xoff, yoff, qx, qy, n, 0, out); }
 static inline void emu_mc_chroma(const FrameDev &F, uint8_t *dst, int ds, int plane, int cx, int cy, int mvx, int mvy, int w, int h)
 {
     int dx = mvx & 7, dy = mvy & 7, cA = (8 - dx) * (8 - dy), cB = dx * (8 - dy), cC = (8 - dx) * dy, cD = dx * dy;
@@ -69,6 +75,7 @@ static inline void prim_cost_chroma_uv(const FrameDev &F, MBLocal *L, const uint
         r[p] = emu_cmp(w, h, enc + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
     }
     *cu = r[0]; *cv = r[1];
+    if (F.trace && L->mb_xy == F.trace_mb) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = 4 | satd | (enc == L->recb ? 2 : 0); t[6] = *cu; t[7] = *cv; F.trace[0] = k + 1; } }
 }
 static inline int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {

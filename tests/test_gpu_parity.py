@@ -75,7 +75,7 @@ def test_block_costs_match_oracle(pc):
         ip = i % 7
         xo, yo = offs[ip][i % len(offs[ip])]
         req.append([int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16)), ip, xo, yo,
-                    int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), i % 2])
+                    int(rng.integers(-40, 40)), int(rng.integers(-40, 40)), i % 2])
     got = enc.block_costs(26, req)
     L = orc.lib()
     fy, fu, fv = [np.ascontiguousarray(a) for a in clip[1]]
@@ -95,6 +95,15 @@ def test_block_costs_match_oracle(pc):
                                 cpl.shape[1], mx, my, w // 2, h // 2)
                 e2 = C.c_void_p(fpl.ctypes.data + (mby * 8 + yo // 2) * (W // 2) + mbx * 8 + xo // 2)
                 assert fn(ip + 3, e2, W // 2, d2.ctypes.data_as(C.c_void_p), w // 2) == g3[1 + pl], ("chroma", pl, ip, mx, my, satd)
+    # batched evaluation (4 candidates per wavefront): answers must equal the single-candidate ones
+    breq = [[r[0], r[1], r[2], r[3], r[4], r[5], r[6], (r[7] & 1) | 2] for r in req[:300]]
+    bgot = enc.block_costs(26, breq)
+    sreq = []
+    for r in breq:
+        for dx, dy in ((1, -1), (-2, 3), (3, 2)):
+            sreq.append([r[0], r[1], r[2], r[3], r[4], r[5] + dx, r[6] + dy, r[7] & 1])
+    sgot = enc.block_costs(26, sreq)[:, 0].reshape(-1, 3)
+    assert np.array_equal(bgot, sgot), np.argwhere(bgot != sgot)[:5]
     enc.close(); o.close()
 
 

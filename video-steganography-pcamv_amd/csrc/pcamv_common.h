@@ -36,6 +36,7 @@ enum { PIX_16x16, PIX_16x8, PIX_8x16, PIX_8x8, PIX_8x4, PIX_4x8, PIX_4x4 };
 struct FrameDev {
     int w, h, mb_w, mb_h, n_mb;
     int stride, lines, cstride, clines;
+    long long plane_size;          /* stride*lines: the four luma planes are contiguous, plane k = luma[0] + k*plane_size */
     const uint8_t *fenc[3];
     uint8_t *luma[4];              /* picture-origin pointers into the padded planes */
     uint8_t *chroma[2];
@@ -59,6 +60,7 @@ struct FrameDev {
     int q_mf[2][3], q_bias[2][3], dq_mf[3];    /* [0] luma inter, [1] chroma inter; at qp / chroma_qp */
     int dq_mf_c[3];
     int lambda2_chroma;            /* x264_lambda2_tab[chroma_qp] for the skip-probe SSD threshold */
+    int *trace; int trace_mb;      /* diagnostics: log every block-cost evaluation of one MB (trace[0] = count) */
 };
 
 PCAMV_CONST int pix_w_tab[7] = {16, 16, 8, 8, 8, 4, 4};
@@ -97,6 +99,10 @@ struct MBLocal {
     uint8_t sub_part[4];
     int b_skip_mc, cbp_luma, cbp_chroma;
     int red[64];                   /* scratch for cross-lane work */
+    int candx[12], candy[12];      /* predictor candidates of the running search (always fully initialised) */
+    int mvc16[9][2];               /* candidate MVs of the 16x16 search */
+    int nbc[12];                   /* neighbourhood costs of the RCA step */
+    int slots[16];
 };
 #define NB_LEFT 1
 #define NB_TOP 2

@@ -25,13 +25,16 @@ struct pcamv_ctx {
     int n_diag, slots_per_mb;
     /* device allocations */
     uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_chroma[2], *d_rec[3];
-    int8_t *d_mb_type, *d_ref8, *d_prev_ref;
-    int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux;
+    const uint8_t *ref_src[3];       /* raw reference planes the next plane production reads (d_raw or caller's device memory) */
+    int8_t *d_mb_type, *d_ref8, *d_prev_ref, *d_ref8_b;
+    int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux, *d_mv_b;
+    int pp, prev_internal;      /* ping-pong of the motion field for device-resident chains */
     pcamv_mb_t *d_rec_mb;
     int16_t *d_cost_mv[52];
     uint8_t *d_cover, *d_stego, *d_message, *d_blk_which, *d_user_msg;
     float *d_rho; int8_t *d_flip; int *d_hdr, *d_rnd; unsigned *d_cols, *d_path; long long *d_lcg;
     int cap;
+    int *d_trace;
     /* stc extractor LCG replay */
     long long lcg_before_last_embed;
     /* timing of the search phase */
@@ -102,6 +105,8 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     HIPCHK(c, dalloc(&c->d_chroma[0], csz + 64)); HIPCHK(c, dalloc(&c->d_chroma[1], csz + 64));
     HIPCHK(c, dalloc(&c->d_mb_type, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_ref8, (size_t)F.n_mb * 4)); HIPCHK(c, dalloc(&c->d_prev_ref, (size_t)F.n_mb * 4));
     HIPCHK(c, dalloc(&c->d_mv, (size_t)F.n_mb * 32)); HIPCHK(c, dalloc(&c->d_prev_mv, (size_t)F.n_mb * 32));
+    HIPCHK(c, dalloc(&c->d_mv_b, (size_t)F.n_mb * 32)); HIPCHK(c, dalloc(&c->d_ref8_b, (size_t)F.n_mb * 4));
+    HIPCHK(c, hipMemset(c->d_mv_b, 0, (size_t)F.n_mb * 64)); HIPCHK(c, hipMemset(c->d_ref8_b, 0xff, (size_t)F.n_mb * 4));
     HIPCHK(c, dalloc(&c->d_mvr, (size_t)F.n_mb * 2)); HIPCHK(c, dalloc(&c->d_mvp_aux, (size_t)F.n_mb * 32));
     HIPCHK(c, dalloc(&c->d_rec_mb, (size_t)F.n_mb));
     HIPCHK(c, hipMemset(c->d_rec_mb, 0, (size_t)F.n_mb * sizeof(pcamv_mb_t)));
@@ -143,7 +148,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
     hipFree(c->d_luma); hipFree(c->d_chroma[0]); hipFree(c->d_chroma[1]);
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
-    hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb);
+    hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb); hipFree(c->d_mv_b); hipFree(c->d_ref8_b);
     for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);
     hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_blk_which); hipFree(c->d_user_msg); hipFree(c->d_rho);
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
@@ -175,7 +180,7 @@ extern "C" int pcamv_gpu_upload_fenc(pcamv_ctx_t *c, const uint8_t *const plane[
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 3; i++) {
         int w = c->F.w >> !!i, h = c->F.h >> !!i;
-        HIPCHK(c, hipMemcpy2DAsync(c->d_fenc[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2D(c->d_fenc[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice));   /* caller memory is pageable: blocking copy */
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -207,14 +212,15 @@ extern "C" int pcamv_gpu_set_ref(pcamv_ctx_t *c, const uint8_t *const plane[3], 
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 3; i++) {
         int w = c->F.w >> !!i, h = c->F.h >> !!i;
-        HIPCHK(c, hipMemcpy2DAsync(c->d_raw[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2D(c->d_raw[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice));
     }
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
     c->F.prev_mv = c->d_prev_mv; c->F.prev_ref = c->d_prev_ref;
     if (c->F.have_prev) {
-        HIPCHK(c, hipMemcpyAsync(c->d_prev_mv, prev_mv, (size_t)c->F.n_mb * 64, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_prev_ref, prev_ref, (size_t)c->F.n_mb * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy(c->d_prev_mv, prev_mv, (size_t)c->F.n_mb * 64, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_prev_ref, prev_ref, (size_t)c->F.n_mb * 4, hipMemcpyHostToDevice));
     }
+    for (int i = 0; i < 3; i++) c->ref_src[i] = c->d_raw[i];
     int rc = launch_plane_production(c, c->d_raw[0], c->d_raw[1], c->d_raw[2], c->stream);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -225,12 +231,11 @@ extern "C" int pcamv_gpu_set_ref_device(pcamv_ctx_t *c, const void *y, const voi
     if (!c || !y || !u || !v) return PCAMV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
-    if (c->F.have_prev) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; }
-    /* the filter itself runs as the first kernels of the next step (plane production is part of the timed path) */
-    c->d_raw[0] = c->d_raw[0];
-    HIPCHK(c, hipMemcpyAsync(c->d_raw[0], y, (size_t)c->F.w * c->F.h, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_raw[1], u, (size_t)c->F.w * c->F.h / 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_raw[2], v, (size_t)c->F.w * c->F.h / 4, hipMemcpyDeviceToDevice, c->stream));
+    c->prev_internal = prev_mv == PCAMV_PREV_FIELD_INTERNAL;
+    if (c->F.have_prev && !c->prev_internal) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; }
+    /* the filter itself runs as the first kernels of the next step (plane production is part of the
+     * timed path) and reads the caller's planes in place */
+    c->ref_src[0] = (const uint8_t *)y; c->ref_src[1] = (const uint8_t *)u; c->ref_src[2] = (const uint8_t *)v;
     return 0;
 }
 
@@ -248,6 +253,11 @@ extern "C" int pcamv_gpu_get_ref_planes(pcamv_ctx_t *c, uint8_t *out, int *strid
 static int launch_analysis(pcamv_ctx *c, int embed, hipStream_t st, int timed)
 {
     c->F.embed = embed;
+    if (c->prev_internal) {      /* this frame writes field pp, reads the field the previous frame wrote */
+        c->F.mv = c->pp ? c->d_mv_b : c->d_mv; c->F.ref8 = c->pp ? c->d_ref8_b : c->d_ref8;
+        c->F.prev_mv = c->pp ? c->d_mv : c->d_mv_b; c->F.prev_ref = c->pp ? c->d_ref8 : c->d_ref8_b;
+        c->pp ^= 1;
+    }
     const FrameDev F = c->F;
     int slot = -1;
     if (timed) { slot = c->ev_head; hipEventRecord(c->ev0[slot], st); }
@@ -283,19 +293,19 @@ extern "C" int pcamv_gpu_analyse_pframe(pcamv_ctx_t *c, int qp, int embed, pcamv
     int rc = ensure_qp(c, qp);
     if (rc) return rc;
     if ((rc = launch_analysis(c, embed, c->stream, 1))) return rc;
-    HIPCHK(c, hipMemcpyAsync(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
     if (recon)
         for (int i = 0; i < 3; i++)
-            if (recon[i]) HIPCHK(c, hipMemcpyAsync(recon[i], c->d_rec[i], ((size_t)c->F.w * c->F.h) >> (i ? 2 : 0), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (recon[i]) HIPCHK(c, hipMemcpy(recon[i], c->d_rec[i], ((size_t)c->F.w * c->F.h) >> (i ? 2 : 0), hipMemcpyDeviceToHost));
     return 0;
 }
 
 static int fetch_embed(pcamv_ctx *c, pcamv_embed_t *out)
 {
     int hdr[8];
-    HIPCHK(c, hipMemcpyAsync(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
     out->n = hdr[0]; out->m = hdr[1]; out->stc_ok = hdr[2]; out->num_flip = hdr[3];
     if (out->n > c->cap || out->m > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
     if (out->cover) HIPCHK(c, hipMemcpy(out->cover, c->d_cover, out->n, hipMemcpyDeviceToHost));
@@ -313,7 +323,7 @@ extern "C" int pcamv_gpu_embed_pframe(pcamv_ctx_t *c, float emrate, const uint8_
     HIPCHK(c, hipMemcpy(&c->lcg_before_last_embed, c->d_lcg, sizeof(long long), hipMemcpyDeviceToHost));
     if (message) {
         if (message_len < 0 || message_len > c->cap) return fail(c, PCAMV_EINVAL, "message_len");
-        HIPCHK(c, hipMemcpyAsync(c->d_user_msg, message, message_len, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy(c->d_user_msg, message, message_len, hipMemcpyHostToDevice));
         c->E.user_message = c->d_user_msg; c->E.user_message_len = message_len;
     } else { c->E.user_message = NULL; c->E.user_message_len = 0; }
     int rc = launch_embed(c, emrate, c->stream);
@@ -328,7 +338,8 @@ extern "C" int pcamv_gpu_step_device(pcamv_ctx_t *c, int qp, float emrate, void 
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     int rc = ensure_qp(c, qp);
     if (rc) return rc;
-    if ((rc = launch_plane_production(c, c->d_raw[0], c->d_raw[1], c->d_raw[2], st))) return rc;
+    if (!c->ref_src[0]) return fail(c, PCAMV_EINVAL, "no reference set");
+    if ((rc = launch_plane_production(c, c->ref_src[0], c->ref_src[1], c->ref_src[2], st))) return rc;
     if ((rc = launch_analysis(c, emrate > 0, st, 1))) return rc;
     if (emrate > 0) { c->E.user_message = NULL; c->E.user_message_len = 0; if ((rc = launch_embed(c, emrate, st))) return rc; }
     return 0;
@@ -356,6 +367,27 @@ extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double 
     if (avg_ms) *avg_ms = c->t_search_launches ? c->t_search_ms / c->t_search_launches : 0;
     if (launches) *launches = c->t_search_launches;
     if (reset) { c->t_search_ms = 0; c->t_search_launches = 0; }
+    return 0;
+}
+
+/* diagnostics: log every block-cost evaluation made for macroblock mb during the next analyse call
+ * into a device buffer; fetch with pcamv_gpu_trace_fetch.  mb < 0 switches tracing off. */
+extern "C" int pcamv_gpu_trace_mb(pcamv_ctx_t *c, int mb)
+{
+    if (!c) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mb < 0) { c->F.trace = NULL; return 0; }
+    if (!c->d_trace) HIPCHK(c, dalloc(&c->d_trace, (size_t)1 + 8 * 4000));
+    HIPCHK(c, hipMemset(c->d_trace, 0, (1 + 8 * 4000) * sizeof(int)));
+    c->F.trace = c->d_trace; c->F.trace_mb = mb;
+    return 0;
+}
+extern "C" int pcamv_gpu_trace_fetch(pcamv_ctx_t *c, int32_t *out /* 1 + 8*4000 */)
+{
+    if (!c || !out || !c->d_trace) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_trace, (1 + 8 * 4000) * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -27,6 +27,15 @@ __global__ void __launch_bounds__(256) k_chroma_pad(const uint8_t *__restrict__ 
     dst[(size_t)y * cstride + x] = src[(size_t)sy * w + sx];
 }
 
+/* clamp to [0,255] of an already shifted value.  The empty asm keeps hipcc (ROCm 7.2) from fusing
+ * shift + clamp of two neighbours into v_ashr_pk_u8_i32: the code it emits around that gfx950
+ * instruction ORs further bytes into the destination assuming bits [31:16] come back zero, but
+ * the hardware leaves the old contents there (seen as wrong bytes 2/3 of every packed dword). */
+__device__ __forceinline__ uint32_t clamp_u8(int v)
+{
+    asm volatile("" : "+v"(v));
+    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
 #define HT_W 64
 #define HT_H 16
 __global__ void __launch_bounds__(256) k_hpel(const uint8_t *__restrict__ src, uint8_t *__restrict__ planes, int W, int H, int stride, int lines)
@@ -70,9 +79,9 @@ __global__ void __launch_bounds__(256) k_hpel(const uint8_t *__restrict__ src, u
             const int16_t *vr = &s_v[r][c];
             int tc = vr[-2] + vr[3] - 5 * (vr[-1] + vr[2]) + 20 * (vr[0] + vr[1]);
             of |= (uint32_t)f << (8 * k);
-            oh |= (uint32_t)clip3i((th + 16) >> 5, 0, 255) << (8 * k);
-            ov |= (uint32_t)clip3i((vr[0] + 16) >> 5, 0, 255) << (8 * k);
-            oc |= (uint32_t)clip3i((tc + 512) >> 10, 0, 255) << (8 * k);
+            oh |= clamp_u8((th + 16) >> 5) << (8 * k);
+            ov |= clamp_u8((vr[0] + 16) >> 5) << (8 * k);
+            oc |= clamp_u8((tc + 512) >> 10) << (8 * k);
         }
         if (x0 + tx < stride) {
             size_t o = (size_t)y * stride + x0 + tx;
@@ -119,6 +128,12 @@ __global__ void __launch_bounds__(64) k_block_costs(FrameDev F, const int *__res
     const int *r = req + 8 * blockIdx.x;
     L.mb_x = r[0]; L.mb_y = r[1]; L.mb_xy = r[1] * F.mb_w + r[0];
     prim_load_fenc(F, &L);
+    if (r[7] & 2) {     /* batch mode: 4 candidates around (mx,my) at once; answer = 3 of them */
+        int bx[4] = {r[5], r[5] + 1, r[5] - 2, r[5] + 3}, by[4] = {r[6], r[6] - 1, r[6] + 3, r[6] + 2}, o4[4] = {0, 0, 0, 0};
+        prim_cost_luma_xn(F, &L, L.fenc, r[2], r[3], r[4], bx, by, 4, r[7] & 1, o4);
+        if (LANE() == 0) { out[3 * blockIdx.x] = o4[1]; out[3 * blockIdx.x + 1] = o4[2]; out[3 * blockIdx.x + 2] = o4[3]; }
+        return;
+    }
     int luma = prim_cost_luma(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7]);
     int cu = 0, cv = 0;
     if (r[2] <= PIX_8x8) prim_cost_chroma_uv(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7], &cu, &cv);

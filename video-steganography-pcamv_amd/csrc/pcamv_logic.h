@@ -76,7 +76,7 @@ PCAMV_DEV void predict_mv_pskip(MBLocal *L, int mv[2])
 }
 /* candidate MVs for the 16x16 search: spatial 16x16 results of non-skipped neighbours, then the
  * co-located / right / below MVs of the previous frame scaled by POC distance */
-PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int mvc[9][2])
+PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
 {
     int i = 0, xy = L->mb_xy, top = xy - F.mb_w;
 #define SETMV(mb) { mvc[i][0] = F.mvr[2 * (mb)]; mvc[i][1] = F.mvr[2 * (mb) + 1]; i++; }
@@ -179,15 +179,15 @@ struct SearchCtx {
 PCAMV_DEV void fpel_try(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
                         const int *mx, const int *my, int n, int *costs_out)
 {
-    int c[4];
+    int c[4] = {0, 0, 0, 0};
     prim_sad_fpel_xn(F, L, me->i_pixel, me->xoff, me->yoff, mx, my, n, c);
     for (int k = 0; k < n; k++) {
-        c[k] += MVCOSTX(mx[k] << 2) + MVCOSTY(my[k] << 2);
+        c[k] += MVCOSTX(mx[k] * 4) + MVCOSTY(my[k] * 4);
         if (costs_out) costs_out[k] = c[k];
         else if (c[k] < bcost) { bcost = c[k]; bmx = mx[k]; bmy = my[k]; }
     }
 }
-#define TRY1(X, Y) { int tx_[1] = {X}, ty_[1] = {Y}; fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 1, 0); }
+#define TRY1(X, Y) { int tx_[4] = {X, X, X, X}, ty_[4] = {Y, Y, Y, Y}; fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 1, 0); }
 #define TRY4(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1) { \
         int tx_[4] = {(ox) + (a0), (ox) + (b0), (ox) + (c0), (ox) + (d0)}, ty_[4] = {(oy) + (a1), (oy) + (b1), (oy) + (c1), (oy) + (d1)}; \
         fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 4, 0); }
@@ -221,7 +221,7 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
         }
     }
     for (int i = hpel_iters; i > 0; i--) {
-        int omx = bmx, omy = bmy, c[4];
+        int omx = bmx, omy = bmy, c[4] = {0, 0, 0, 0};
         int cx[4] = {omx, omx, omx - 2, omx + 2}, cy[4] = {omy - 2, omy + 2, omy, omy};
         prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, 0, c);
         c[0] += MVCOSTX(omx) + MVCOSTY(omy - 2); if (c[0] < bcost) { bcost = c[0]; bmy = omy - 2; }
@@ -240,7 +240,7 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
     bdir = -1;
     for (int i = qpel_iters; i > 0; i--) {
         odir = bdir;
-        int omx = bmx, omy = bmy, lc[4];
+        int omx = bmx, omy = bmy, lc[4] = {0, 0, 0, 0};
         int cx[4] = {omx, omx, omx - 1, omx + 1}, cy[4] = {omy - 1, omy + 1, omy, omy};
         prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, satd, lc);
         for (int k = 0; k < 4; k++) {
@@ -288,7 +288,7 @@ PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, 
     int costs[6], dir = -2;
     {
         int tx[4] = {bmx - 2, bmx - 1, bmx + 1, bmx + 2}, ty[4] = {bmy, bmy + 2, bmy + 2, bmy};
-        int ux[2] = {bmx + 1, bmx - 1}, uy[2] = {bmy - 2, bmy - 2};
+        int ux[4] = {bmx + 1, bmx - 1, bmx, bmx}, uy[4] = {bmy - 2, bmy - 2, bmy, bmy};
         fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 4, costs);
         fpel_try(F, L, me, bmx, bmy, bcost, ux, uy, 2, costs + 4);
     }
@@ -297,8 +297,8 @@ PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, 
         bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
         for (int i = 1; i < i_me_range / 2 && CHECK_MVRANGE(bmx, bmy); i++) {
             const int odir = mod6m1_tab[dir + 1];
-            int tx[3] = {bmx + hex2_tab[odir][0], bmx + hex2_tab[odir + 1][0], bmx + hex2_tab[odir + 2][0]};
-            int ty[3] = {bmy + hex2_tab[odir][1], bmy + hex2_tab[odir + 1][1], bmy + hex2_tab[odir + 2][1]};
+            int tx[4] = {bmx + hex2_tab[odir][0], bmx + hex2_tab[odir + 1][0], bmx + hex2_tab[odir + 2][0], bmx};
+            int ty[4] = {bmy + hex2_tab[odir][1], bmy + hex2_tab[odir + 1][1], bmy + hex2_tab[odir + 2][1], bmy};
             fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 3, costs);
             dir = -2;
             if (costs[0] < bcost) { bcost = costs[0]; dir = odir - 1; }
@@ -327,27 +327,31 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
 
     if (F.subme >= 3) {
         /* qpel-precision test of the predictor and the candidates (plain SAD) */
-        int cx[10], cy[10], n = 0, sx = bmx, sy = bmy;
-        cx[n] = bmx; cy[n] = bmy; n++;
+        int n = 0, sx = bmx, sy = bmy;
+        for (int i = 0; i < 12; i++) { L->candx[i] = bmx; L->candy[i] = bmy; }
+        n = 1;
         for (int i = 0; i < i_mvc; i++)
             if ((mvc[i][0] | mvc[i][1]) && ((sx - mvc[i][0]) | (sy - mvc[i][1]))) {
-                cx[n] = clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4);
-                cy[n] = clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4);
+                L->candx[n] = clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4);
+                L->candy[n] = clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4);
                 n++;
             }
         for (int b = 0; b < n; b += 4) {
-            int c[4], nn = imin(4, n - b);
-            prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx + b, cy + b, nn, 0, c);
-            for (int k = 0; k < nn; k++) {
-                int cc = c[k] + MVCOSTX(cx[b + k]) + MVCOSTY(cy[b + k]);
-                if (cc < bpred_cost) { bpred_cost = cc; bpred_mx = cx[b + k]; bpred_my = cy[b + k]; }
+            int c[4] = {0, 0, 0, 0}, nn = imin(4, n - b);
+            int qx[4] = {L->candx[b], L->candx[b + 1], L->candx[b + 2], L->candx[b + 3]};
+            int qy[4] = {L->candy[b], L->candy[b + 1], L->candy[b + 2], L->candy[b + 3]};
+            prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, qx, qy, nn, 0, c);
+            for (int k = 0; k < 4; k++) {
+                if (k >= nn) break;
+                int cc = c[k] + MVCOSTX(qx[k]) + MVCOSTY(qy[k]);
+                if (cc < bpred_cost) { bpred_cost = cc; bpred_mx = qx[k]; bpred_my = qy[k]; }
             }
         }
         bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
         TRY1(bmx, bmy);
     } else {
         TRY1(pmx, pmy);
-        bcost -= MVCOSTX(pmx << 2) + MVCOSTY(pmy << 2);
+        bcost -= MVCOSTX(pmx * 4) + MVCOSTY(pmy * 4);
         for (int i = 0; i < i_mvc; i++) {
             int mx = (mvc[i][0] + 2) >> 2, my = (mvc[i][1] + 2) >> 2;
             if ((mx | my) && ((mx - bmx) | (my - bmy))) {
@@ -433,7 +437,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     }
 
     if (bpred_cost < bcost) { me->mv[0] = bpred_mx; me->mv[1] = bpred_my; me->cost = bpred_cost; }
-    else { me->mv[0] = bmx << 2; me->mv[1] = bmy << 2; me->cost = bcost; }
+    else { me->mv[0] = bmx * 4; me->mv[1] = bmy * 4; me->cost = bcost; }
     me->cost_mv = MVCOSTX(me->mv[0]) + MVCOSTY(me->mv[1]);
     if (bmx == pmx && bmy == pmy && F.subme < 3) me->cost += me->cost_mv;
     if (F.subme >= 2) refine_subpel(F, L, me, subpel_iter_tab[F.subme][2], subpel_iter_tab[F.subme][3], 0);
@@ -576,11 +580,12 @@ PCAMV_DEV void update_cache(MBLocal *L, Analysis *a)
 
 PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_try_pskip)
 {
-    MEState me; int mvc[9][2];
+    MEState me;
     me_setup(&me, PIX_16x16, 0, 0);
     predict_mv_16x16(L, 0, me.mvp);
-    int i_mvc = predict_mv_ref16x16(F, L, mvc);
-    me_search(F, L, &me, mvc, i_mvc);
+    for (int i = 0; i < 9; i++) { L->mvc16[i][0] = 0; L->mvc16[i][1] = 0; }
+    int i_mvc = predict_mv_ref16x16(F, L, L->mvc16);
+    me_search(F, L, &me, L->mvc16, i_mvc);
     if (b_try_pskip && me.cost - me.cost_mv < 300 * F.lambda &&
         iabs(me.mv[0] - L->pskip_mv[0]) + iabs(me.mv[1] - L->pskip_mv[1]) <= 1 && probe_pskip(F, L)) {
         L->i_type = PCAMV_P_SKIP;
@@ -690,18 +695,19 @@ PCAMV_CONST signed char d_mv_tab[12][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-2
 PCAMV_CONST signed char d_nb_tab[9][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {0, 0}};
 
 /* nine neighbourhood costs around (cx,cy) on the current reconstruction; returns min, last in *last */
-PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, int cx, int cy, int *nb_cost, int *last)
+PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, int cx, int cy, int nb_cost, int *last)
 {
     int mn = PCAMV_COST_MAX, c = 0;
-    int lc[12], qx[12], qy[12];
-    for (int k = 0; k < 9; k++) { qx[k] = cx + d_nb_tab[k][0]; qy[k] = cy + d_nb_tab[k][1]; }
-    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx, qy, 4, F.subme > 1, lc);
-    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx + 4, qy + 4, 4, F.subme > 1, lc + 4);
-    prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx + 8, qy + 8, 1, F.subme > 1, lc + 8);
-    for (int k = 0; k < 9; k++) {
-        c = mv_satd_rec(F, L, me, lc[k], qx[k], qy[k]);
-        if (nb_cost) nb_cost[k] = c;
-        if (c < mn) mn = c;
+    for (int b = 0; b < 9; b += 4) {
+        int qx[4], qy[4], lc[4] = {0, 0, 0, 0}, nn = imin(4, 9 - b);
+        for (int k = 0; k < 4; k++) { int kk = imin(b + k, 8); qx[k] = cx + d_nb_tab[kk][0]; qy[k] = cy + d_nb_tab[kk][1]; }
+        prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx, qy, nn, F.subme > 1, lc);
+        for (int k = 0; k < 4; k++) {
+            if (k >= nn) break;
+            c = mv_satd_rec(F, L, me, lc[k], qx[k], qy[k]);
+            if (nb_cost) L->nbc[b + k] = c;
+            if (c < mn) mn = c;
+        }
     }
     *last = c;
     return mn;
@@ -711,11 +717,11 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
 {
     const float beta1 = 1.4, beta2 = 4;
     int bmx = me->mv[0], bmy = me->mv[1];
-    int cost = 0, min_cost, nb_cost[9];
+    int cost = 0, min_cost;
     int b_1_neighbor = 0, b_error_pos = 0;
     update_cache(L, a); mb_encode(F, L); prim_copy_pred_to_rec(L);
-    min_cost = rca_nine(F, L, me, bmx, bmy, nb_cost, &cost);
-    me->cost_rec = nb_cost[8];
+    min_cost = rca_nine(F, L, me, bmx, bmy, 1, &cost);
+    me->cost_rec = L->nbc[8];
     const int want_optimal = !(min_cost < me->cost_rec);
     min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
     int ii_best = -1;
@@ -731,7 +737,7 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
     if (min_cost == PCAMV_COST_MAX) {
         b_error_pos = 1; b_1_neighbor = 1;
         *m_x = 0; *m_y = 0;
-        for (int k = 0; k < 4; k++) if (nb_cost[k] < min_cost) { min_cost = nb_cost[k]; *m_x = d_nb_tab[k][0]; *m_y = d_nb_tab[k][1]; }
+        for (int k = 0; k < 4; k++) if (L->nbc[k] < min_cost) { min_cost = L->nbc[k]; *m_x = d_nb_tab[k][0]; *m_y = d_nb_tab[k][1]; }
     } else b_1_neighbor = ii_best <= 3;
     int cost_opt = min_cost > me->cost_rec ? min_cost - me->cost_rec : 1;
     if (!b_1_neighbor) cost_opt = (int)(beta1 * (float)cost_opt);

@@ -25,7 +25,7 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
     mb_load(F, L, mb_x, mb_y);
     analyse_mb_search(F, L, a);
     const int xy = L->mb_xy;
-    int slots[16];
+    int *slots = L->slots;
     const int used = F.embed && L->i_type != PCAMV_P_SKIP;
     const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, used, slots);
     if (PCAMV_LANE0) {
@@ -60,7 +60,7 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
 }
 
 /* rebuild the decided partitioning (types, MVs, search-time mvp) from the record */
-PCAMV_DEV int analysis_from_record(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int slots[16])
+PCAMV_DEV int analysis_from_record(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int *slots)
 {
     const pcamv_mb_t *r = &F.rec_mb[xy];
     mb_load(F, L, xy % F.mb_w, xy / F.mb_w);
@@ -81,7 +81,7 @@ PCAMV_DEV int analysis_from_record(const FrameDev &F, MBLocal *L, Analysis *a, i
 PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k)
 {
     if (!F.rec_mb[xy].used) return;
-    int slots[16];
+    int *slots = L->slots;
     const int n = analysis_from_record(F, L, a, xy, slots);
     if (k >= n) return;
     MEState *me = slot_me(L, a, slots[k]);
@@ -97,8 +97,7 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
 
 PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
 {
-    int slots[16];
-    analysis_from_record(F, L, a, xy, slots);
+    analysis_from_record(F, L, a, xy, L->slots);
     update_cache(L, a);
     mb_encode(F, L);
     prim_store_rec(F, L);

@@ -51,9 +51,10 @@ __device__ __forceinline__ QpelPos qpel_pos(const FrameDev &F, int px, int py, i
     QpelPos q;
     int qidx = ((mvy & 3) << 2) + (mvx & 3);
     ptrdiff_t off = (ptrdiff_t)(py + (mvy >> 2)) * F.stride + px + (mvx >> 2);
-    q.a = F.luma[hpel_ref0_tab[qidx]] + off + ((mvy & 3) == 3) * F.stride;
+    /* plane chosen by pointer arithmetic: the index is lane-varying, F lives in scalar registers */
+    q.a = F.luma[0] + (ptrdiff_t)hpel_ref0_tab[qidx] * F.plane_size + off + ((mvy & 3) == 3) * F.stride;
     q.two = (qidx & 5) != 0;
-    q.b = F.luma[hpel_ref1_tab[qidx]] + off + ((mvx & 3) == 3);
+    q.b = F.luma[0] + (ptrdiff_t)hpel_ref1_tab[qidx] * F.plane_size + off + ((mvx & 3) == 3);
     return q;
 }
 __device__ __forceinline__ uint32_t qpel_row(const QpelPos &q, const FrameDev &F, int r)
@@ -112,18 +113,23 @@ __device__ __forceinline__ void prim_cost_luma_xn(const FrameDev &F, MBLocal *L,
         else v >>= 1;
     }
     v = group_sum(v, nblk);
-    for (int c = 0; c < n; c++) out[c] = __builtin_amdgcn_readlane(v, c * nblk);
+    out[0] = __builtin_amdgcn_readlane(v, 0);
+    if (n > 1) out[1] = __builtin_amdgcn_readlane(v, nblk);
+    if (n > 2) out[2] = __builtin_amdgcn_readlane(v, 2 * nblk);
+    if (n > 3) out[3] = __builtin_amdgcn_readlane(v, 3 * nblk);
+    if (F.trace && L->mb_xy == F.trace_mb && lane == 0)
+        for (int c = 0; c < n; c++) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx[c]; t[4] = my[c]; t[5] = satd | (enc == L->recb ? 2 : 0); t[6] = out[c]; t[7] = 0; F.trace[0] = k + 1; } }
 }
 __device__ __forceinline__ int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
 {
-    int o[1], ax[1] = {mx}, ay[1] = {my};
+    int o[4] = {0, 0, 0, 0}, ax[4] = {mx, mx, mx, mx}, ay[4] = {my, my, my, my};
     prim_cost_luma_xn(F, L, enc, ip, xoff, yoff, ax, ay, 1, satd, o);
     return o[0];
 }
 __device__ __forceinline__ void prim_sad_fpel_xn(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int *out)
 {
-    int qx[4], qy[4];
-    for (int k = 0; k < n; k++) { qx[k] = mx[k] << 2; qy[k] = my[k] << 2; }
+    int qx[4], qy[4];      /* callers always pass 4 initialised entries */
+    for (int k = 0; k < 4; k++) { qx[k] = mx[k] * 4; qy[k] = my[k] * 4; }
     prim_cost_luma_xn(F, L, L->fenc, ip, xoff, yoff, qx, qy, n, 0, out);
 }
 
@@ -132,7 +138,7 @@ __device__ __forceinline__ uint32_t chroma_row4(const FrameDev &F, int plane, in
 {
     int dx = mvx & 7, dy = mvy & 7;
     int cA = (8 - dx) * (8 - dy), cB = dx * (8 - dy), cC = (8 - dx) * dy, cD = dx * dy;
-    const uint8_t *s = F.chroma[plane] + (ptrdiff_t)(cy + (mvy >> 3)) * F.cstride + cx + (mvx >> 3);
+    const uint8_t *s = (plane ? F.chroma[1] : F.chroma[0]) + (ptrdiff_t)(cy + (mvy >> 3)) * F.cstride + cx + (mvx >> 3);
     uint32_t a0 = ld4u(s), a1 = s[4], b0 = ld4u(s + F.cstride), b1 = s[F.cstride + 4];
     uint32_t o = 0;
 #pragma unroll
@@ -170,6 +176,7 @@ __device__ __forceinline__ void prim_cost_chroma_uv(const FrameDev &F, MBLocal *
     v = group_sum(v, nb);
     *cu = __builtin_amdgcn_readlane(v, 0);
     *cv = __builtin_amdgcn_readlane(v, nb);
+    if (F.trace && L->mb_xy == F.trace_mb && lane == 0) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = 4 | satd | (enc == L->recb ? 2 : 0); t[6] = *cu; t[7] = *cv; F.trace[0] = k + 1; } }
 }
 __device__ __forceinline__ int prim_cost_chroma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int plane, int mx, int my, int satd)
 {

@@ -252,7 +252,17 @@ class Encoder:
         self._chk(self.lib.pcamv_gpu_block_costs(self.ctx, qp, len(req), _p(req), _p(out)), "block_costs")
         return out
 
+    def trace_mb(self, mb):
+        self._chk(self.lib.pcamv_gpu_trace_mb(self.ctx, mb), "trace_mb")
+
+    def trace_fetch(self):
+        out = np.zeros(1 + 8 * 4000, np.int32)
+        self._chk(self.lib.pcamv_gpu_trace_fetch(self.ctx, _p(out)), "trace_fetch")
+        return out[1:1 + 8 * out[0]].reshape(-1, 8)
+
     # device-resident path (bench.py): raw device pointers as integers
+    PREV_INTERNAL = 1
+
     def set_ref_device(self, y, u, v, prev_mv=0, prev_ref=0):
         self._chk(self.lib.pcamv_gpu_set_ref_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v),
                                                     C.c_void_p(prev_mv or None), C.c_void_p(prev_ref or None)), "set_ref_device")
