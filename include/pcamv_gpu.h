@@ -108,6 +108,7 @@ typedef struct pcamv_embed_t {
 } pcamv_embed_t;
 
 typedef struct pcamv_ctx pcamv_ctx_t;
+typedef struct pcamv_batch pcamv_batch_t;
 
 int  pcamv_gpu_open(const pcamv_params_t *param, int device, pcamv_ctx_t **ctx);
 void pcamv_gpu_close(pcamv_ctx_t *ctx);
@@ -159,6 +160,17 @@ int pcamv_gpu_set_fenc_device(pcamv_ctx_t *ctx, const void *y, const void *u, co
  * stay on the device until pcamv_gpu_fetch_results. stream = hipStream_t as void*. */
 int pcamv_gpu_step_device(pcamv_ctx_t *ctx, int qp, float emrate, void *stream);
 int pcamv_gpu_fetch_results(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb, pcamv_embed_t *out);
+/* Batches: several contexts (independent closed GOPs of the same size on the same device) advance
+ * one frame per step together; every kernel launch then carries the same dependency step of all
+ * of them.  A single 1080p frame exposes at most 60 independent macroblocks at a time,
+ * the batch is what fills the 256 CUs.  The contexts keep their own inputs/outputs (set_ref_device,
+ * set_fenc_device, fetch_results); the batch only owns the launch descriptors. */
+int  pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_batch_t **batch);
+void pcamv_gpu_batch_destroy(pcamv_batch_t *batch);
+int  pcamv_gpu_batch_step(pcamv_batch_t *batch, int qp, float emrate, void *stream);
+int  pcamv_gpu_batch_kernel_time(pcamv_batch_t *batch, const char *kernel, double *avg_ms, int *launches, int reset);
+const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *batch);
+
 /* Average duration in ms of the dominant kernel over the launches since the last reset,
  * measured with hipEvents on the launch stream (bench.py roofline). */
 int pcamv_gpu_kernel_time(pcamv_ctx_t *ctx, const char *kernel, double *avg_ms, int *launches, int reset);

@@ -38,6 +38,8 @@ struct FrameDev {
     int stride, lines, cstride, clines;
     long long plane_size;          /* stride*lines: the four luma planes are contiguous, plane k = luma[0] + k*plane_size */
     const uint8_t *fenc[3];
+    const uint8_t *raw[3];         /* un-padded reference planes the plane-production kernels read */
+    uint8_t *luma_base, *chroma_base[2];   /* start of the padded allocations */
     uint8_t *luma[4];              /* picture-origin pointers into the padded planes */
     uint8_t *chroma[2];
     uint8_t *rec[3];               /* pass-1 reconstruction out, tightly packed */

@@ -15,17 +15,34 @@
 
 #define PCAMV_ABI_VERSION 1
 #define NEV 32
+#define NRING 8
+
+struct pcamv_ctx;
+/* A batch = the set of independent closed-GOP contexts whose frames advance together: every kernel
+ * launch carries the same dependency step of all of them (descriptor arrays in device memory). */
+struct pcamv_batch {
+    int n, device, n_diag, slots_per_mb, max_diag;
+    int W, H;
+    pcamv_ctx **ctx;
+    FrameDev *h_F, *d_F;        /* NRING slots of n descriptors (pinned host / device) */
+    EmbedDev *h_E, *d_E;
+    hipEvent_t slot_done[NRING];
+    int slot_used[NRING], head;
+    hipEvent_t ev0[NEV], ev1[NEV];
+    int ev_n, ev_head;
+    double t_search_ms; int t_search_launches;
+    char err[256];
+};
 
 struct pcamv_ctx {
     pcamv_params_t p;
     int device;
     hipStream_t stream;
+    pcamv_batch *self;          /* batch of one, used by the per-context entry points */
     FrameDev F;
     EmbedDev E;
-    int n_diag, slots_per_mb;
     /* device allocations */
     uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_chroma[2], *d_rec[3];
-    const uint8_t *ref_src[3];       /* raw reference planes the next plane production reads (d_raw or caller's device memory) */
     int8_t *d_mb_type, *d_ref8, *d_prev_ref, *d_ref8_b;
     int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux, *d_mv_b;
     int pp, prev_internal;      /* ping-pong of the motion field for device-resident chains */
@@ -35,12 +52,6 @@ struct pcamv_ctx {
     float *d_rho; int8_t *d_flip; int *d_hdr, *d_rnd; unsigned *d_cols, *d_path; long long *d_lcg;
     int cap;
     int *d_trace;
-    /* stc extractor LCG replay */
-    long long lcg_before_last_embed;
-    /* timing of the search phase */
-    hipEvent_t ev0[NEV], ev1[NEV];
-    int ev_n, ev_head;
-    double t_search_ms; int t_search_launches;
     char err[256];
 };
 
@@ -49,7 +60,13 @@ static int fail(pcamv_ctx *c, int code, const char *fmt, ...)
     if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof(c->err), fmt, ap); va_end(ap); }
     return code;
 }
+static int bfail(pcamv_batch *b, int code, const char *fmt, ...)
+{
+    if (b) { va_list ap; va_start(ap, fmt); vsnprintf(b->err, sizeof(b->err), fmt, ap); va_end(ap); }
+    return code;
+}
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, PCAMV_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define HIPCHKB(b, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bfail(b, PCAMV_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 extern "C" const char *pcamv_gpu_last_error(const pcamv_ctx_t *c) { return c ? c->err : "no context"; }
@@ -76,6 +93,54 @@ static void glibc_srand_state(int *st, unsigned seed)
     }
     st[31] = f; st[32] = b;
 }
+
+/* ------------------------------------------------------------------ batches */
+extern "C" void pcamv_gpu_batch_destroy(pcamv_batch_t *b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    if (b->h_F) hipHostFree(b->h_F);
+    if (b->h_E) hipHostFree(b->h_E);
+    hipFree(b->d_F); hipFree(b->d_E);
+    for (int i = 0; i < NRING; i++) if (b->slot_done[i]) hipEventDestroy(b->slot_done[i]);
+    for (int i = 0; i < NEV; i++) { if (b->ev0[i]) hipEventDestroy(b->ev0[i]); if (b->ev1[i]) hipEventDestroy(b->ev1[i]); }
+    free(b->ctx);
+    delete b;
+}
+
+extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_batch_t **out)
+{
+    if (!ctxs || n <= 0 || !out) return PCAMV_EINVAL;
+    *out = NULL;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device || ctxs[i]->F.w != ctxs[0]->F.w || ctxs[i]->F.h != ctxs[0]->F.h ||
+            ctxs[i]->p.inter != ctxs[0]->p.inter) return PCAMV_EINVAL;
+    pcamv_batch *b = new (std::nothrow) pcamv_batch();
+    if (!b) return PCAMV_ENOMEM;
+    memset((void *)b, 0, sizeof(*b));
+    b->n = n; b->device = ctxs[0]->device; b->W = ctxs[0]->F.w; b->H = ctxs[0]->F.h;
+    b->ctx = (pcamv_ctx **)malloc(sizeof(pcamv_ctx *) * n);
+    for (int i = 0; i < n; i++) b->ctx[i] = ctxs[i];
+    const FrameDev &F = ctxs[0]->F;
+    b->n_diag = F.mb_w + 2 * (F.mb_h - 1);
+    b->max_diag = (F.mb_w + 1) / 2 < F.mb_h ? (F.mb_w + 1) / 2 : F.mb_h;
+    b->slots_per_mb = (ctxs[0]->p.inter & PCAMV_ANALYSE_PSUB8x8) ? 16 : 2;
+    hipError_t e = hipSetDevice(b->device);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_F, sizeof(FrameDev) * n * NRING, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_E, sizeof(EmbedDev) * n * NRING, hipHostMallocDefault);
+    if (e == hipSuccess) e = dalloc(&b->d_F, (size_t)n * NRING);
+    if (e == hipSuccess) e = dalloc(&b->d_E, (size_t)n * NRING);
+    for (int i = 0; i < NRING && e == hipSuccess; i++) e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
+    for (int i = 0; i < NEV && e == hipSuccess; i++) { e = hipEventCreate(&b->ev0[i]); if (e == hipSuccess) e = hipEventCreate(&b->ev1[i]); }
+    if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
+    *out = b;
+    return 0;
+}
+extern "C" const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *b) { return b ? b->err : "no batch"; }
+
+/* ------------------------------------------------------------------ contexts */
+extern "C" void pcamv_gpu_close(pcamv_ctx_t *c);
 
 extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t **out)
 {
@@ -122,20 +187,20 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     int rnd[40]; memset(rnd, 0, sizeof(rnd)); glibc_srand_state(rnd, 1);
     HIPCHK(c, hipMemcpy(c->d_rnd, rnd, sizeof(rnd), hipMemcpyHostToDevice));
     long long lcg = 1; HIPCHK(c, hipMemcpy(c->d_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
-    c->lcg_before_last_embed = 1;
-    for (int i = 0; i < 3; i++) { F.fenc[i] = c->d_fenc[i]; F.rec[i] = c->d_rec[i]; }
+    for (int i = 0; i < 3; i++) { F.fenc[i] = c->d_fenc[i]; F.rec[i] = c->d_rec[i]; F.raw[i] = c->d_raw[i]; }
+    F.luma_base = c->d_luma; F.chroma_base[0] = c->d_chroma[0]; F.chroma_base[1] = c->d_chroma[1];
     for (int k = 0; k < 4; k++) F.luma[k] = c->d_luma + k * lsz + (size_t)F.stride * PCAMV_PAD + PCAMV_PAD;
     for (int k = 0; k < 2; k++) F.chroma[k] = c->d_chroma[k] + (size_t)F.cstride * PCAMV_CPAD + PCAMV_CPAD;
     F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
     F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
     F.rec_mb = c->d_rec_mb; F.mvp_aux = c->d_mvp_aux;
-    c->n_diag = F.mb_w + 2 * (F.mb_h - 1);
-    c->slots_per_mb = (p->inter & PCAMV_ANALYSE_PSUB8x8) ? 16 : 2;
     EmbedDev &E = c->E;
     E.mbs = c->d_rec_mb; E.n_mb = F.n_mb; E.cover = c->d_cover; E.stego = c->d_stego; E.message = c->d_message; E.rho = c->d_rho;
     E.flip = c->d_flip; E.hdr = c->d_hdr; E.blk_which = c->d_blk_which; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
     E.lcg = c->d_lcg; E.cap = c->cap; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
-    for (int i = 0; i < NEV; i++) { HIPCHK(c, hipEventCreate(&c->ev0[i])); HIPCHK(c, hipEventCreate(&c->ev1[i])); }
+    pcamv_ctx *one[1] = {c};
+    int rc = pcamv_gpu_batch_create(one, 1, &c->self);
+    if (rc) { pcamv_gpu_close(c); return rc; }
     *out = c;
     return 0;
 }
@@ -144,7 +209,8 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();
+    if (c->self) pcamv_gpu_batch_destroy(c->self);
     for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
     hipFree(c->d_luma); hipFree(c->d_chroma[0]); hipFree(c->d_chroma[1]);
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
@@ -152,7 +218,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);
     hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_blk_which); hipFree(c->d_user_msg); hipFree(c->d_rho);
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
-    for (int i = 0; i < NEV; i++) { hipEventDestroy(c->ev0[i]); hipEventDestroy(c->ev1[i]); }
+    if (c->d_trace) hipFree(c->d_trace);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -181,8 +247,8 @@ extern "C" int pcamv_gpu_upload_fenc(pcamv_ctx_t *c, const uint8_t *const plane[
     for (int i = 0; i < 3; i++) {
         int w = c->F.w >> !!i, h = c->F.h >> !!i;
         HIPCHK(c, hipMemcpy2D(c->d_fenc[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice));   /* caller memory is pageable: blocking copy */
+        c->F.fenc[i] = c->d_fenc[i];
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 extern "C" int pcamv_gpu_set_fenc_device(pcamv_ctx_t *c, const void *y, const void *u, const void *v)
@@ -192,17 +258,77 @@ extern "C" int pcamv_gpu_set_fenc_device(pcamv_ctx_t *c, const void *y, const vo
     return 0;
 }
 
-/* plane production on the stream: raw Y/U/V (device) -> padded full/H/V/HV + padded chroma */
-static int launch_plane_production(pcamv_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v, hipStream_t st)
+/* ------------------------------------------------------------------ batched launches */
+/* take the next descriptor slot, fill it from the contexts' current FrameDev/EmbedDev and queue its upload */
+static int batch_push_descs(pcamv_batch *b, hipStream_t st, const FrameDev **dF, const EmbedDev **dE, int *slot_out)
 {
-    const FrameDev &F = c->F;
-    dim3 g((F.stride + HT_W - 1) / HT_W, (F.lines + HT_H - 1) / HT_H);
-    hipLaunchKernelGGL(k_hpel, g, dim3(256), 0, st, y, c->d_luma, F.w, F.h, F.stride, F.lines);
-    dim3 gc((F.cstride + 255) / 256, F.clines);
-    hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, u, c->d_chroma[0], F.w / 2, F.h / 2, F.cstride, F.clines);
-    hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, v, c->d_chroma[1], F.w / 2, F.h / 2, F.cstride, F.clines);
+    int slot = b->head;
+    b->head = (b->head + 1) % NRING;
+    if (b->slot_used[slot]) HIPCHKB(b, hipEventSynchronize(b->slot_done[slot]));    /* descriptors of this slot no longer in flight */
+    FrameDev *hF = b->h_F + (size_t)slot * b->n; EmbedDev *hE = b->h_E + (size_t)slot * b->n;
+    for (int i = 0; i < b->n; i++) { hF[i] = b->ctx[i]->F; hE[i] = b->ctx[i]->E; }
+    HIPCHKB(b, hipMemcpyAsync(b->d_F + (size_t)slot * b->n, hF, sizeof(FrameDev) * b->n, hipMemcpyHostToDevice, st));
+    HIPCHKB(b, hipMemcpyAsync(b->d_E + (size_t)slot * b->n, hE, sizeof(EmbedDev) * b->n, hipMemcpyHostToDevice, st));
+    *dF = b->d_F + (size_t)slot * b->n; *dE = b->d_E + (size_t)slot * b->n; *slot_out = slot;
+    return 0;
+}
+static int batch_release_slot(pcamv_batch *b, int slot, hipStream_t st)
+{
+    HIPCHKB(b, hipEventRecord(b->slot_done[slot], st));
+    b->slot_used[slot] = 1;
+    return 0;
+}
+
+/* what: bit0 plane production, bit1 analysis (search+RCA+encode), bit2 embedding */
+static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
+{
+    HIPCHKB(b, hipSetDevice(b->device));
+    for (int i = 0; i < b->n; i++) {
+        pcamv_ctx *c = b->ctx[i];
+        if ((what & 2) && c->prev_internal) {      /* this frame writes field pp, reads the field the previous frame wrote */
+            c->F.mv = c->pp ? c->d_mv_b : c->d_mv; c->F.ref8 = c->pp ? c->d_ref8_b : c->d_ref8;
+            c->F.prev_mv = c->pp ? c->d_mv : c->d_mv_b; c->F.prev_ref = c->pp ? c->d_ref8 : c->d_ref8_b;
+            c->pp ^= 1;
+        }
+    }
+    const FrameDev *dF; const EmbedDev *dE; int slot;
+    int rc = batch_push_descs(b, st, &dF, &dE, &slot);
+    if (rc) return rc;
+    const FrameDev &F = b->ctx[0]->F;
+    const unsigned G = (unsigned)b->n;
+    if (what & 1) {
+        dim3 g((F.stride + HT_W - 1) / HT_W, (F.lines + HT_H - 1) / HT_H, G);
+        hipLaunchKernelGGL(k_hpel, g, dim3(256), 0, st, dF);
+        dim3 gc((F.cstride + 255) / 256, F.clines, 2 * G);
+        hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, dF);
+    }
+    if (what & 2) {
+        int ev = -1;
+        if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
+        for (int d = 0; d < b->n_diag; d++) {
+            int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+            int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+            int cnt = y_hi - y_lo + 1;
+            if (cnt <= 0) continue;
+            hipLaunchKernelGGL(k_search_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+        }
+        if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
+        hipLaunchKernelGGL(k_rca, dim3(F.n_mb * b->slots_per_mb, G), dim3(64), 0, st, dF, b->slots_per_mb);
+        hipLaunchKernelGGL(k_encode, dim3(F.n_mb, G), dim3(64), 0, st, dF);
+    }
+    if (what & 4) {
+        hipLaunchKernelGGL(k_embed_prepare, dim3(G), dim3(1024), 0, st, dE);
+        hipLaunchKernelGGL(k_stc_forward, dim3(G), dim3(1024), 0, st, dE);
+        hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
+    }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "plane production launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return bfail(b, PCAMV_EHIP, "kernel launch: %s", hipGetErrorString(e));
+    return batch_release_slot(b, slot, st);
+}
+static int ctx_launch(pcamv_ctx *c, int what)
+{
+    int rc = batch_launch(c->self, what, c->stream, 1);
+    if (rc) { snprintf(c->err, sizeof(c->err), "%s", c->self->err); return rc; }
     return 0;
 }
 
@@ -213,15 +339,17 @@ extern "C" int pcamv_gpu_set_ref(pcamv_ctx_t *c, const uint8_t *const plane[3], 
     for (int i = 0; i < 3; i++) {
         int w = c->F.w >> !!i, h = c->F.h >> !!i;
         HIPCHK(c, hipMemcpy2D(c->d_raw[i], w, plane[i], stride[i], w, h, hipMemcpyHostToDevice));
+        c->F.raw[i] = c->d_raw[i];
     }
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
+    c->prev_internal = 0;
+    c->F.mv = c->d_mv; c->F.ref8 = c->d_ref8;
     c->F.prev_mv = c->d_prev_mv; c->F.prev_ref = c->d_prev_ref;
     if (c->F.have_prev) {
         HIPCHK(c, hipMemcpy(c->d_prev_mv, prev_mv, (size_t)c->F.n_mb * 64, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_prev_ref, prev_ref, (size_t)c->F.n_mb * 4, hipMemcpyHostToDevice));
     }
-    for (int i = 0; i < 3; i++) c->ref_src[i] = c->d_raw[i];
-    int rc = launch_plane_production(c, c->d_raw[0], c->d_raw[1], c->d_raw[2], c->stream);
+    int rc = ctx_launch(c, 1);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -229,13 +357,12 @@ extern "C" int pcamv_gpu_set_ref(pcamv_ctx_t *c, const uint8_t *const plane[3], 
 extern "C" int pcamv_gpu_set_ref_device(pcamv_ctx_t *c, const void *y, const void *u, const void *v, const void *prev_mv, const void *prev_ref)
 {
     if (!c || !y || !u || !v) return PCAMV_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
     c->prev_internal = prev_mv == PCAMV_PREV_FIELD_INTERNAL;
-    if (c->F.have_prev && !c->prev_internal) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; }
+    if (c->F.have_prev && !c->prev_internal) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; c->F.mv = c->d_mv; c->F.ref8 = c->d_ref8; }
     /* the filter itself runs as the first kernels of the next step (plane production is part of the
      * timed path) and reads the caller's planes in place */
-    c->ref_src[0] = (const uint8_t *)y; c->ref_src[1] = (const uint8_t *)u; c->ref_src[2] = (const uint8_t *)v;
+    c->F.raw[0] = (const uint8_t *)y; c->F.raw[1] = (const uint8_t *)u; c->F.raw[2] = (const uint8_t *)v;
     return 0;
 }
 
@@ -243,46 +370,10 @@ extern "C" int pcamv_gpu_get_ref_planes(pcamv_ctx_t *c, uint8_t *out, int *strid
 {
     if (!c || !out) return PCAMV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(out, c->d_luma, 4 * (size_t)c->F.stride * c->F.lines, hipMemcpyDeviceToHost));
     if (stride) *stride = c->F.stride;
     if (lines) *lines = c->F.lines;
-    return 0;
-}
-
-static int launch_analysis(pcamv_ctx *c, int embed, hipStream_t st, int timed)
-{
-    c->F.embed = embed;
-    if (c->prev_internal) {      /* this frame writes field pp, reads the field the previous frame wrote */
-        c->F.mv = c->pp ? c->d_mv_b : c->d_mv; c->F.ref8 = c->pp ? c->d_ref8_b : c->d_ref8;
-        c->F.prev_mv = c->pp ? c->d_mv : c->d_mv_b; c->F.prev_ref = c->pp ? c->d_ref8 : c->d_ref8_b;
-        c->pp ^= 1;
-    }
-    const FrameDev F = c->F;
-    int slot = -1;
-    if (timed) { slot = c->ev_head; hipEventRecord(c->ev0[slot], st); }
-    for (int d = 0; d < c->n_diag; d++) {
-        int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-        int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
-        int cnt = y_hi - y_lo + 1;
-        if (cnt <= 0) continue;
-        hipLaunchKernelGGL(k_search_diag, dim3(cnt), dim3(64), 0, st, F, d);
-    }
-    if (timed) { hipEventRecord(c->ev1[slot], st); c->ev_head = (c->ev_head + 1) % NEV; if (c->ev_n < NEV) c->ev_n++; }
-    if (embed) hipLaunchKernelGGL(k_rca, dim3(F.n_mb * c->slots_per_mb), dim3(64), 0, st, F, c->slots_per_mb);
-    hipLaunchKernelGGL(k_encode, dim3(F.n_mb), dim3(64), 0, st, F);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "analysis launch: %s", hipGetErrorString(e));
-    return 0;
-}
-static int launch_embed(pcamv_ctx *c, float emrate, hipStream_t st)
-{
-    c->E.emrate = emrate;
-    hipLaunchKernelGGL(k_embed_prepare, dim3(1), dim3(1024), 0, st, c->E);
-    hipLaunchKernelGGL(k_stc_forward, dim3(1), dim3(1024), 0, st, c->E);
-    hipLaunchKernelGGL(k_stc_backward, dim3(1), dim3(64), 0, st, c->E);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "embed launch: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -292,7 +383,8 @@ extern "C" int pcamv_gpu_analyse_pframe(pcamv_ctx_t *c, int qp, int embed, pcamv
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_qp(c, qp);
     if (rc) return rc;
-    if ((rc = launch_analysis(c, embed, c->stream, 1))) return rc;
+    c->F.embed = embed;
+    if ((rc = ctx_launch(c, 2))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
     if (recon)
@@ -304,15 +396,15 @@ extern "C" int pcamv_gpu_analyse_pframe(pcamv_ctx_t *c, int qp, int embed, pcamv
 static int fetch_embed(pcamv_ctx *c, pcamv_embed_t *out)
 {
     int hdr[8];
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
     out->n = hdr[0]; out->m = hdr[1]; out->stc_ok = hdr[2]; out->num_flip = hdr[3];
-    if (out->n > c->cap || out->m > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
-    if (out->cover) HIPCHK(c, hipMemcpy(out->cover, c->d_cover, out->n, hipMemcpyDeviceToHost));
-    if (out->rho) HIPCHK(c, hipMemcpy(out->rho, c->d_rho, (size_t)out->n * 4, hipMemcpyDeviceToHost));
-    if (out->stego) HIPCHK(c, hipMemcpy(out->stego, c->d_stego, out->n, hipMemcpyDeviceToHost));
-    if (out->flip) HIPCHK(c, hipMemcpy(out->flip, c->d_flip, out->n, hipMemcpyDeviceToHost));
-    if (out->message) HIPCHK(c, hipMemcpy(out->message, c->d_message, out->m, hipMemcpyDeviceToHost));
+    if (out->n < 0 || out->m < 0 || out->n > c->cap || out->m > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
+    if (out->cover && out->n) HIPCHK(c, hipMemcpy(out->cover, c->d_cover, out->n, hipMemcpyDeviceToHost));
+    if (out->rho && out->n) HIPCHK(c, hipMemcpy(out->rho, c->d_rho, (size_t)out->n * 4, hipMemcpyDeviceToHost));
+    if (out->stego && out->n) HIPCHK(c, hipMemcpy(out->stego, c->d_stego, out->n, hipMemcpyDeviceToHost));
+    if (out->flip && out->n) HIPCHK(c, hipMemcpy(out->flip, c->d_flip, out->n, hipMemcpyDeviceToHost));
+    if (out->message && out->m) HIPCHK(c, hipMemcpy(out->message, c->d_message, out->m, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -320,29 +412,38 @@ extern "C" int pcamv_gpu_embed_pframe(pcamv_ctx_t *c, float emrate, const uint8_
 {
     if (!c || !out || emrate <= 0) return PCAMV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(&c->lcg_before_last_embed, c->d_lcg, sizeof(long long), hipMemcpyDeviceToHost));
     if (message) {
         if (message_len < 0 || message_len > c->cap) return fail(c, PCAMV_EINVAL, "message_len");
         HIPCHK(c, hipMemcpy(c->d_user_msg, message, message_len, hipMemcpyHostToDevice));
         c->E.user_message = c->d_user_msg; c->E.user_message_len = message_len;
     } else { c->E.user_message = NULL; c->E.user_message_len = 0; }
-    int rc = launch_embed(c, emrate, c->stream);
+    c->E.emrate = emrate;
+    int rc = ctx_launch(c, 4);
     if (rc) return rc;
     return fetch_embed(c, out);
 }
 
+/* one step of every context of the batch on resident inputs: plane production + analysis + embedding */
+extern "C" int pcamv_gpu_batch_step(pcamv_batch_t *b, int qp, float emrate, void *stream)
+{
+    if (!b) return PCAMV_EINVAL;
+    HIPCHKB(b, hipSetDevice(b->device));
+    for (int i = 0; i < b->n; i++) {
+        pcamv_ctx *c = b->ctx[i];
+        int rc = ensure_qp(c, qp);
+        if (rc) return bfail(b, rc, "%s", c->err);
+        if (!c->F.raw[0]) return bfail(b, PCAMV_EINVAL, "context %d has no reference", i);
+        c->F.embed = emrate > 0; c->E.emrate = emrate; c->E.user_message = NULL; c->E.user_message_len = 0;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : b->ctx[0]->stream;
+    return batch_launch(b, emrate > 0 ? 7 : 3, st, 1);
+}
 extern "C" int pcamv_gpu_step_device(pcamv_ctx_t *c, int qp, float emrate, void *stream)
 {
     if (!c) return PCAMV_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    int rc = ensure_qp(c, qp);
-    if (rc) return rc;
-    if (!c->ref_src[0]) return fail(c, PCAMV_EINVAL, "no reference set");
-    if ((rc = launch_plane_production(c, c->ref_src[0], c->ref_src[1], c->ref_src[2], st))) return rc;
-    if ((rc = launch_analysis(c, emrate > 0, st, 1))) return rc;
-    if (emrate > 0) { c->E.user_message = NULL; c->E.user_message_len = 0; if ((rc = launch_embed(c, emrate, st))) return rc; }
-    return 0;
+    int rc = pcamv_gpu_batch_step(c->self, qp, emrate, stream ? stream : (void *)c->stream);
+    if (rc) snprintf(c->err, sizeof(c->err), "%s", c->self->err);
+    return rc;
 }
 extern "C" int pcamv_gpu_fetch_results(pcamv_ctx_t *c, pcamv_mb_t *out_mb, pcamv_embed_t *out)
 {
@@ -354,20 +455,29 @@ extern "C" int pcamv_gpu_fetch_results(pcamv_ctx_t *c, pcamv_mb_t *out_mb, pcamv
     return 0;
 }
 
+static int batch_kernel_time(pcamv_batch *b, double *avg_ms, int *launches, int reset)
+{
+    HIPCHKB(b, hipSetDevice(b->device));
+    HIPCHKB(b, hipDeviceSynchronize());
+    for (int i = 0; i < b->ev_n; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]) == hipSuccess) { b->t_search_ms += ms; b->t_search_launches += b->n_diag; }
+    }
+    b->ev_n = 0; b->ev_head = 0;
+    if (avg_ms) *avg_ms = b->t_search_launches ? b->t_search_ms / b->t_search_launches : 0;
+    if (launches) *launches = b->t_search_launches;
+    if (reset) { b->t_search_ms = 0; b->t_search_launches = 0; }
+    return 0;
+}
+extern "C" int pcamv_gpu_batch_kernel_time(pcamv_batch_t *b, const char *kernel, double *avg_ms, int *launches, int reset)
+{
+    if (!b || !kernel || strcmp(kernel, "k_search_diag")) return PCAMV_EINVAL;
+    return batch_kernel_time(b, avg_ms, launches, reset);
+}
 extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double *avg_ms, int *launches, int reset)
 {
     if (!c || !kernel || strcmp(kernel, "k_search_diag")) return PCAMV_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    for (int i = 0; i < c->ev_n; i++) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess) { c->t_search_ms += ms; c->t_search_launches += c->n_diag; }
-    }
-    c->ev_n = 0; c->ev_head = 0;
-    if (avg_ms) *avg_ms = c->t_search_launches ? c->t_search_ms / c->t_search_launches : 0;
-    if (launches) *launches = c->t_search_launches;
-    if (reset) { c->t_search_ms = 0; c->t_search_launches = 0; }
-    return 0;
+    return batch_kernel_time(c->self, avg_ms, launches, reset);
 }
 
 /* diagnostics: log every block-cost evaluation made for macroblock mb during the next analyse call
@@ -403,13 +513,14 @@ extern "C" int pcamv_gpu_block_costs(pcamv_ctx_t *c, int qp, int n, const int32_
     }
     int rc = ensure_qp(c, qp);
     if (rc) return rc;
-    int *d_req = NULL, *d_out = NULL;
-    HIPCHK(c, dalloc(&d_req, (size_t)n * 8)); HIPCHK(c, dalloc(&d_out, (size_t)n * 3));
+    int *d_req = NULL, *d_out = NULL; FrameDev *d_F = NULL;
+    HIPCHK(c, dalloc(&d_req, (size_t)n * 8)); HIPCHK(c, dalloc(&d_out, (size_t)n * 3)); HIPCHK(c, dalloc(&d_F, 1));
     HIPCHK(c, hipMemcpy(d_req, req, (size_t)n * 8 * sizeof(int), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_block_costs, dim3(n), dim3(64), 0, c->stream, c->F, d_req, d_out);
+    HIPCHK(c, hipMemcpy(d_F, &c->F, sizeof(FrameDev), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_block_costs, dim3(n), dim3(64), 0, c->stream, (const FrameDev *)d_F, (const int *)d_req, d_out);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost));
-    hipFree(d_req); hipFree(d_out);
+    hipFree(d_req); hipFree(d_out); hipFree(d_F);
     return 0;
 }
 

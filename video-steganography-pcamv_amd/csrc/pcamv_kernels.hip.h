@@ -19,8 +19,17 @@
 #include "stc_mats.h"
 
 /* ------------------------------------------------------------------ plane production */
-__global__ void __launch_bounds__(256) k_chroma_pad(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, int cstride, int clines)
+/* Every kernel is batched over independent closed GOPs: blockIdx.z (plane kernels) or blockIdx.y
+ * (macroblock kernels) selects the GOP's FrameDev in a device array.  One launch then carries
+ * the same dependency step of all GOPs, which is what fills the 256 CUs (a single 1080p frame
+ * exposes at most 60 independent macroblocks at a time). */
+__global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__restrict__ Fs)
 {
+    const FrameDev &F = Fs[blockIdx.z >> 1];
+    const int pl = blockIdx.z & 1;
+    const uint8_t *__restrict__ src = F.raw[1 + pl];
+    uint8_t *__restrict__ dst = F.chroma_base[pl];
+    const int w = F.w >> 1, h = F.h >> 1, cstride = F.cstride, clines = F.clines;
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= cstride || y >= clines) return;
     int sx = clip3i(x - PCAMV_CPAD, 0, w - 1), sy = clip3i(y - PCAMV_CPAD, 0, h - 1);
@@ -38,8 +47,12 @@ __device__ __forceinline__ uint32_t clamp_u8(int v)
 }
 #define HT_W 64
 #define HT_H 16
-__global__ void __launch_bounds__(256) k_hpel(const uint8_t *__restrict__ src, uint8_t *__restrict__ planes, int W, int H, int stride, int lines)
+__global__ void __launch_bounds__(256) k_hpel(const FrameDev *__restrict__ Fs)
 {
+    const FrameDev &F = Fs[blockIdx.z];
+    const uint8_t *__restrict__ src = F.raw[0];
+    uint8_t *__restrict__ planes = F.luma_base;
+    const int W = F.w, H = F.h, stride = F.stride, lines = F.lines;
     __shared__ uint8_t s_src[HT_H + 5][HT_W + 8];
     __shared__ int16_t s_v[HT_H][HT_W + 8];
     const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H;          /* padded-plane coordinates */
@@ -94,37 +107,42 @@ __global__ void __launch_bounds__(256) k_hpel(const uint8_t *__restrict__ src, u
 }
 
 /* ------------------------------------------------------------------ analysis phases */
-__global__ void __launch_bounds__(64) k_search_diag(FrameDev F, int d)
+__global__ void __launch_bounds__(64) k_search_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
+    const FrameDev F = Fs[blockIdx.y];
     /* MBs of the anti-diagonal x + 2y = d */
     int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
     int y = y_lo + (int)blockIdx.x, x = d - 2 * y;
     if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
     mbk_search(F, &L, &A, x, y);
 }
-__global__ void __launch_bounds__(64) k_rca(FrameDev F, int slots_per_mb)
+__global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int slots_per_mb)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
+    const FrameDev F = Fs[blockIdx.y];
+    if (!F.embed) return;
     int xy = blockIdx.x / slots_per_mb, k = blockIdx.x - xy * slots_per_mb;
     if (xy >= F.n_mb) return;
     mbk_rca(F, &L, &A, xy, k);
 }
-__global__ void __launch_bounds__(64) k_encode(FrameDev F)
+__global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
+    const FrameDev F = Fs[blockIdx.y];
     if ((int)blockIdx.x >= F.n_mb) return;
     mbk_encode(F, &L, &A, blockIdx.x);
 }
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */
-__global__ void __launch_bounds__(64) k_block_costs(FrameDev F, const int *__restrict__ req, int *__restrict__ out)
+__global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__ Fs, const int *__restrict__ req, int *__restrict__ out)
 {
     __shared__ MBLocal L;
+    const FrameDev F = Fs[0];
     const int *r = req + 8 * blockIdx.x;
     L.mb_x = r[0]; L.mb_y = r[1]; L.mb_xy = r[1] * F.mb_w + r[0];
     prim_load_fenc(F, &L);
@@ -189,8 +207,9 @@ __device__ int dev_stc_matrix(int width, int height, unsigned *cols, long long *
     return 1;
 }
 
-__global__ void __launch_bounds__(1024) k_embed_prepare(EmbedDev E)
+__global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restrict__ Es)
 {
+    const EmbedDev E = Es[blockIdx.x];
     __shared__ int s_cnt[1024];
     const int t = threadIdx.x;
     const int chunk = (E.n_mb + 1023) / 1024;
@@ -281,8 +300,9 @@ __global__ void __launch_bounds__(1024) k_embed_prepare(EmbedDev E)
 /* forward Viterbi: thread = trellis state.  new[s] = min(p[s] + c_stay, p[s^col] + c_flip), path bit
  * set when the flip branch is <= (embed.h:439-467 evaluated per state; ties and infinities behave
  * identically because both formulations add and compare the same two floats). */
-__global__ void __launch_bounds__(1024) k_stc_forward(EmbedDev E)
+__global__ void __launch_bounds__(1024) k_stc_forward(const EmbedDev *__restrict__ Es)
 {
+    const EmbedDev E = Es[blockIdx.x];
     __shared__ float s_p[2][1024];
     __shared__ float s_rho[256];
     __shared__ uint8_t s_cov[256];
@@ -332,8 +352,9 @@ __global__ void __launch_bounds__(1024) k_stc_forward(EmbedDev E)
     (void)n;
 }
 
-__global__ void __launch_bounds__(64) k_stc_backward(EmbedDev E)
+__global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__restrict__ Es)
 {
+    const EmbedDev E = Es[blockIdx.x];
     __shared__ unsigned s_path[64][32];
     __shared__ uint8_t s_out[64];
     const int lane = threadIdx.x;

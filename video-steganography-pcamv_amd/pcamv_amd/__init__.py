@@ -5,8 +5,8 @@ reference's parameter surface for this path (x264_param_default / x264_param_par
 There is no CPU fallback: importing works without a GPU, but every operation raises
 PcamvError when the library or a HIP device is missing.
 """
-from .api import (PcamvError, Params, Encoder, param_default, param_parse, level_mv_range, lib_path, build_library,
+from .api import (PcamvError, Params, Encoder, Batch, param_default, param_parse, level_mv_range, lib_path, build_library,
                   MB_DTYPE, stc_extract, load_library, ME_NAMES, P_L0, P_8x8, P_SKIP)
 
-__all__ = ["PcamvError", "Params", "Encoder", "param_default", "param_parse", "level_mv_range", "lib_path",
+__all__ = ["PcamvError", "Params", "Encoder", "Batch", "param_default", "param_parse", "level_mv_range", "lib_path",
            "build_library", "MB_DTYPE", "stc_extract", "load_library", "ME_NAMES", "P_L0", "P_8x8", "P_SKIP"]

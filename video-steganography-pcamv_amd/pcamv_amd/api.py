@@ -283,3 +283,38 @@ class Encoder:
         ms, n = C.c_double(), C.c_int()
         self._chk(self.lib.pcamv_gpu_kernel_time(self.ctx, kernel.encode(), C.byref(ms), C.byref(n), int(reset)), "kernel_time")
         return ms.value, n.value
+
+
+class Batch:
+    """Several Encoder contexts (independent closed GOPs) stepped together: pcamv_gpu_batch_*."""
+
+    def __init__(self, encoders):
+        self.lib = load_library()
+        self.encs = list(encoders)
+        arr = (C.c_void_p * len(self.encs))(*[e.ctx.value for e in self.encs])
+        b = C.c_void_p()
+        rc = self.lib.pcamv_gpu_batch_create(arr, len(self.encs), C.byref(b))
+        if rc:
+            raise PcamvError(f"pcamv_gpu_batch_create failed: {rc}")
+        self.b = b
+        self.lib.pcamv_gpu_batch_last_error.restype = C.c_char_p
+        self.lib.pcamv_gpu_batch_last_error.argtypes = [C.c_void_p]
+        self.lib.pcamv_gpu_batch_destroy.restype = None
+        self.lib.pcamv_gpu_batch_destroy.argtypes = [C.c_void_p]
+
+    def step(self, qp, emrate, stream=0):
+        rc = self.lib.pcamv_gpu_batch_step(self.b, qp, C.c_float(emrate), C.c_void_p(stream or None))
+        if rc:
+            raise PcamvError(f"batch_step failed ({rc}): {self.lib.pcamv_gpu_batch_last_error(self.b).decode()}")
+
+    def kernel_time(self, kernel="k_search_diag", reset=True):
+        ms, n = C.c_double(), C.c_int()
+        rc = self.lib.pcamv_gpu_batch_kernel_time(self.b, kernel.encode(), C.byref(ms), C.byref(n), int(reset))
+        if rc:
+            raise PcamvError(f"batch_kernel_time failed: {rc}")
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "b", None):
+            self.lib.pcamv_gpu_batch_destroy(self.b)
+            self.b = None
