@@ -164,12 +164,20 @@ int pcamv_gpu_fetch_results(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb, pcamv_embed_t 
  * one frame per step together; every kernel launch then carries the same dependency step of all
  * of them.  A single 1080p frame exposes at most 60 independent macroblocks at a time,
  * the batch is what fills the 256 CUs.  The contexts keep their own inputs/outputs (set_ref_device,
- * set_fenc_device, fetch_results); the batch only owns the launch descriptors. */
+ * set_fenc_device, fetch_results); the batch only owns the launch descriptors and the scheduler
+ * state; destroy a batch before closing its contexts.
+ * Scheduling of the analysis inside a step: by default ONE persistent launch ("k_analyse_flow") in
+ * which ready macroblocks of all GOPs flow through a device queue (search -> publish motion ->
+ * RCA costs -> reconstruction per macroblock); with PCAMV_SCHED=diag in the environment at
+ * batch/context creation, one launch per anti-diagonal ("k_search_diag") followed by RCA and
+ * reconstruction launches.  Results are identical; kernel_time takes the name of the active one. */
 int  pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_batch_t **batch);
 void pcamv_gpu_batch_destroy(pcamv_batch_t *batch);
 int  pcamv_gpu_batch_step(pcamv_batch_t *batch, int qp, float emrate, void *stream);
 int  pcamv_gpu_batch_kernel_time(pcamv_batch_t *batch, const char *kernel, double *avg_ms, int *launches, int reset);
 const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *batch);
+/* name of the analysis kernel the batch's schedule launches ("k_analyse_flow" or "k_search_diag") */
+const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *batch);
 
 /* Average duration in ms of the dominant kernel over the launches since the last reset,
  * measured with hipEvents on the launch stream (bench.py roofline). */

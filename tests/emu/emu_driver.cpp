@@ -39,6 +39,12 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     F.cost_mv = cost + PCAMV_COST_MV_CENTRE;
     MBLocal *L = (MBLocal *)malloc(sizeof(MBLocal));
     Analysis *a = (Analysis *)malloc(sizeof(Analysis));
+    if (diag_order == 2) {  /* dataflow schedule: search, then RCA + reconstruction of the same macroblock, in a dependency-legal order */
+        for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
+            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x); } }
+        free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
+        return 0;
+    }
     if (diag_order) {       /* the order the GPU uses: anti-diagonals x + 2y = d */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
             for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search(F, L, a, x, y); }

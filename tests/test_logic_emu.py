@@ -1,7 +1,8 @@
 """The product's wave-uniform control code (csrc/pcamv_logic.h, pcamv_mbkernels.h), compiled for
 the CPU with scalar primitives (tests/emu/), against the reference-minted fixtures.  This checks on
 the CPU the same search / partition / RCA logic the HIP kernels run, including the anti-diagonal
-processing order and the split into search, RCA and encode phases."""
+processing order and the split into search, RCA and encode phases, and the dataflow schedule's
+per-macroblock search -> RCA -> reconstruction sequence (order 2)."""
 import numpy as np
 import pytest
 
@@ -12,8 +13,9 @@ from emu import emu
 FIX = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
 
 
+@pytest.mark.parametrize("order", [1, 2], ids=["diagonal_phases", "dataflow_fused"])
 @pytest.mark.parametrize("name", FIX)
-def test_control_logic_matches_reference(name):
+def test_control_logic_matches_reference(name, order):
     g = helpers.load(name)
     W, H = int(g["width"]), int(g["height"])
     p = orc.make_params(W, H, me=int(g["me"]), subme=int(g["subme"]), mv_range=int(g["mv_range"]),
@@ -23,7 +25,7 @@ def test_control_logic_matches_reference(name):
         prev = (g[f"f{t}_prev_mv"], g[f"f{t}_prev_ref"]) if f"f{t}_prev_mv" in g else (None, None)
         o.set_ref(g[f"f{t}_ref_y"], g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev)
         mbs, rec = emu.analyse_pframe(orc, p, int(g["qp"]), 1, [g[f"f{t}_fenc_{c}"] for c in "yuv"], o.ref_planes(),
-                                      g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev, diag=1)
+                                      g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev, diag=order)
         helpers.compare_records(g[f"f{t}_mbs"], mbs, f"{name} frame {t}")
         for k, nm in enumerate("yuv"):
             assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"

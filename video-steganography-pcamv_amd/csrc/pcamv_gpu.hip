@@ -31,6 +31,10 @@ struct pcamv_batch {
     hipEvent_t ev0[NEV], ev1[NEV];
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
+    /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
+    int sched_flow, flow_waves;
+    unsigned *d_flow;
+    FlowDev fl;
     char err[256];
 };
 
@@ -39,6 +43,7 @@ struct pcamv_ctx {
     int device;
     hipStream_t stream;
     pcamv_batch *self;          /* batch of one, used by the per-context entry points */
+    pcamv_batch *last;          /* batch that ran this context's most recent analysis */
     FrameDev F;
     EmbedDev E;
     /* device allocations */
@@ -100,9 +105,11 @@ extern "C" void pcamv_gpu_batch_destroy(pcamv_batch_t *b)
     if (!b) return;
     hipSetDevice(b->device);
     hipDeviceSynchronize();
+    for (int i = 0; b->ctx && i < b->n; i++) if (b->ctx[i]->last == b) b->ctx[i]->last = NULL;   /* destroy a batch before its contexts */
     if (b->h_F) hipHostFree(b->h_F);
     if (b->h_E) hipHostFree(b->h_E);
     hipFree(b->d_F); hipFree(b->d_E);
+    if (b->d_flow) hipFree(b->d_flow);
     for (int i = 0; i < NRING; i++) if (b->slot_done[i]) hipEventDestroy(b->slot_done[i]);
     for (int i = 0; i < NEV; i++) { if (b->ev0[i]) hipEventDestroy(b->ev0[i]); if (b->ev1[i]) hipEventDestroy(b->ev1[i]); }
     free(b->ctx);
@@ -133,11 +140,31 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     if (e == hipSuccess) e = dalloc(&b->d_E, (size_t)n * NRING);
     for (int i = 0; i < NRING && e == hipSuccess; i++) e = hipEventCreateWithFlags(&b->slot_done[i], hipEventDisableTiming);
     for (int i = 0; i < NEV && e == hipSuccess; i++) { e = hipEventCreate(&b->ev0[i]); if (e == hipSuccess) e = hipEventCreate(&b->ev1[i]); }
+    /* schedule: PCAMV_SCHED=diag keeps one launch per anti-diagonal (+ separate RCA / encode launches);
+     * the default is the dataflow kernel.  Both are the same per-macroblock code. */
+    const char *sched = getenv("PCAMV_SCHED");
+    b->sched_flow = !(sched && !strcmp(sched, "diag")) && F.n_mb <= 65535 && n <= 65535;
+    if (e == hipSuccess && b->sched_flow) {
+        const size_t total = (size_t)n * F.n_mb;
+        e = dalloc(&b->d_flow, 16 + 2 * total);
+        b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + 16; b->fl.dep = (int *)(b->d_flow + 16 + total);
+        b->fl.total = (unsigned)total; b->fl.spin_limit = 4u << 20;
+        b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1;
+        int per_cu = 0, n_cu = 0;
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow, 64, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device);
+        const char *wv = getenv("PCAMV_FLOW_WAVES");
+        long waves = wv ? atol(wv) : (long)per_cu * n_cu;
+        if (waves < 1) waves = 1;
+        if ((size_t)waves > total) waves = (long)total;
+        b->flow_waves = (int)waves;
+    }
     if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
     *out = b;
     return 0;
 }
 extern "C" const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *b) { return b ? b->err : "no batch"; }
+extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) { return b && b->sched_flow ? "k_analyse_flow" : "k_search_diag"; }
 
 /* ------------------------------------------------------------------ contexts */
 extern "C" void pcamv_gpu_close(pcamv_ctx_t *c);
@@ -304,17 +331,25 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     }
     if (what & 2) {
         int ev = -1;
-        if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-        for (int d = 0; d < b->n_diag; d++) {
-            int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-            int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
-            int cnt = y_hi - y_lo + 1;
-            if (cnt <= 0) continue;
-            hipLaunchKernelGGL(k_search_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+        if (timed && !b->sched_flow) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
+        for (int i = 0; i < b->n; i++) b->ctx[i]->last = b;
+        if (b->sched_flow) {
+            hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
+            if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
+            hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
+            if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
+        } else {
+            for (int d = 0; d < b->n_diag; d++) {
+                int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+                int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+                int cnt = y_hi - y_lo + 1;
+                if (cnt <= 0) continue;
+                hipLaunchKernelGGL(k_search_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+            }
+            if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
+            hipLaunchKernelGGL(k_rca, dim3(F.n_mb * b->slots_per_mb, G), dim3(64), 0, st, dF, b->slots_per_mb);
+            hipLaunchKernelGGL(k_encode, dim3(F.n_mb, G), dim3(64), 0, st, dF);
         }
-        if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
-        hipLaunchKernelGGL(k_rca, dim3(F.n_mb * b->slots_per_mb, G), dim3(64), 0, st, dF, b->slots_per_mb);
-        hipLaunchKernelGGL(k_encode, dim3(F.n_mb, G), dim3(64), 0, st, dF);
     }
     if (what & 4) {
         hipLaunchKernelGGL(k_embed_prepare, dim3(G), dim3(1024), 0, st, dE);
@@ -324,6 +359,15 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(b, PCAMV_EHIP, "kernel launch: %s", hipGetErrorString(e));
     return batch_release_slot(b, slot, st);
+}
+/* after a synchronisation: did the dataflow kernel of the last step give up on a bounded spin? */
+static int flow_check(pcamv_batch *b)
+{
+    if (!b || !b->sched_flow) return 0;
+    unsigned bad = 0;
+    HIPCHKB(b, hipMemcpy(&bad, b->fl.ctr + 2, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) return bfail(b, PCAMV_EHIP, "k_analyse_flow: queue wait timed out (results of the last step are incomplete)");
+    return 0;
 }
 static int ctx_launch(pcamv_ctx *c, int what)
 {
@@ -386,6 +430,7 @@ extern "C" int pcamv_gpu_analyse_pframe(pcamv_ctx_t *c, int qp, int embed, pcamv
     c->F.embed = embed;
     if ((rc = ctx_launch(c, 2))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = flow_check(c->self))) return fail(c, rc, "%s", c->self->err);
     HIPCHK(c, hipMemcpy(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
     if (recon)
         for (int i = 0; i < 3; i++)
@@ -450,6 +495,7 @@ extern "C" int pcamv_gpu_fetch_results(pcamv_ctx_t *c, pcamv_mb_t *out_mb, pcamv
     if (!c) return PCAMV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
+    if (c->last) { int rc = flow_check(c->last); if (rc) return fail(c, rc, "%s", c->last->err); }
     if (out_mb) HIPCHK(c, hipMemcpy(out_mb, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
     if (out) return fetch_embed(c, out);
     return 0;
@@ -459,9 +505,10 @@ static int batch_kernel_time(pcamv_batch *b, double *avg_ms, int *launches, int 
 {
     HIPCHKB(b, hipSetDevice(b->device));
     HIPCHKB(b, hipDeviceSynchronize());
+    { int rc = flow_check(b); if (rc) return rc; }
     for (int i = 0; i < b->ev_n; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]) == hipSuccess) { b->t_search_ms += ms; b->t_search_launches += b->n_diag; }
+        if (hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]) == hipSuccess) { b->t_search_ms += ms; b->t_search_launches += b->sched_flow ? 1 : b->n_diag; }
     }
     b->ev_n = 0; b->ev_head = 0;
     if (avg_ms) *avg_ms = b->t_search_launches ? b->t_search_ms / b->t_search_launches : 0;
@@ -471,12 +518,12 @@ static int batch_kernel_time(pcamv_batch *b, double *avg_ms, int *launches, int 
 }
 extern "C" int pcamv_gpu_batch_kernel_time(pcamv_batch_t *b, const char *kernel, double *avg_ms, int *launches, int reset)
 {
-    if (!b || !kernel || strcmp(kernel, "k_search_diag")) return PCAMV_EINVAL;
+    if (!b || !kernel || strcmp(kernel, b->sched_flow ? "k_analyse_flow" : "k_search_diag")) return PCAMV_EINVAL;
     return batch_kernel_time(b, avg_ms, launches, reset);
 }
 extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double *avg_ms, int *launches, int reset)
 {
-    if (!c || !kernel || strcmp(kernel, "k_search_diag")) return PCAMV_EINVAL;
+    if (!c || !kernel || strcmp(kernel, c->self->sched_flow ? "k_analyse_flow" : "k_search_diag")) return PCAMV_EINVAL;
     return batch_kernel_time(c->self, avg_ms, launches, reset);
 }
 

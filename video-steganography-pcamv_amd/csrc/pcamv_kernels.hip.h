@@ -137,6 +137,91 @@ __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
     mbk_encode(F, &L, &A, blockIdx.x);
 }
 
+/* ------------------------------------------------------------------ dataflow scheduling of the analysis
+ * One persistent launch per frame step instead of one launch per anti-diagonal: macroblock (x,y) of a
+ * GOP becomes ready when (x-1,y) and (x+1,y-1) [or (x,y-1) at the right edge] are done; ready
+ * macroblocks of every GOP in flight go through ONE append-only queue.  A wave pops the next index,
+ * waits for that entry to be published, runs the search, publishes the motion the neighbours need
+ * (agent-scope release), decrements its two successors' dependency counters (the one that reaches 0
+ * is appended to the queue), and then -- off the critical path -- does the macroblock's RCA costs and
+ * pass-1 reconstruction from the state it just produced.  Nothing depends on dispatch order, on
+ * residency or on workgroup->XCD placement: an entry index is only waited for after it was handed out,
+ * entries are appended by waves that are running, and the dependency graph always has a ready node
+ * until everything is done.  Spins are bounded; a timeout raises ctr[2] and every wave drains. */
+struct FlowDev {
+    unsigned *ctr;            /* [0] pop index, [1] append index, [2] error flag */
+    unsigned *queue;          /* total entries; 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
+    int *dep;                 /* [n_gop * n_mb] dependencies still open */
+    unsigned total, spin_limit;
+    int n_gop, n_mb, mb_w, mb_h, fused;
+};
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
+{
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= fl.total) return;
+    int xy = (int)(i % (unsigned)fl.n_mb), x = xy % fl.mb_w, y = xy / fl.mb_w;
+    fl.dep[i] = (x > 0) + (y > 0);
+    fl.queue[i] = i < (unsigned)fl.n_gop ? (i << 16) + 1u : 0u;       /* macroblock 0 of every GOP is ready */
+    if (i == 0) { fl.ctr[0] = 0; fl.ctr[1] = (unsigned)fl.n_gop; fl.ctr[2] = 0; }
+}
+
+__device__ __forceinline__ unsigned flow_bcast(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void flow_done_one(const FlowDev &fl, int slot, unsigned item)
+{
+    if (__hip_atomic_fetch_sub(&fl.dep[slot], 1, RLX_AGENT) == 1) {
+        unsigned t = __hip_atomic_fetch_add(&fl.ctr[1], 1u, RLX_AGENT);
+        __hip_atomic_store(&fl.queue[t], item, RLX_AGENT);
+    }
+}
+
+#ifndef PCAMV_FLOW_OCC
+#define PCAMV_FLOW_OCC 4        /* waves per SIMD the register allocation of the persistent kernel is held to */
+#endif
+__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    const int lane = LANE();
+    for (;;) {
+        unsigned idx = 0;
+        if (lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[0], 1u, RLX_AGENT);
+        idx = flow_bcast(idx);
+        if (idx >= fl.total) break;                        /* every macroblock has been handed out */
+        unsigned item = 0;
+        for (unsigned spins = 0;; spins++) {
+            unsigned v = 0;
+            if (lane == 0) v = __hip_atomic_load(&fl.queue[idx], RLX_AGENT);
+            item = flow_bcast(v);
+            if (item) break;
+            unsigned bad = 0;
+            if ((spins & 255u) == 255u) { if (lane == 0) bad = __hip_atomic_load(&fl.ctr[2], RLX_AGENT); bad = flow_bcast(bad); }
+            if (bad || spins >= fl.spin_limit) break;
+            if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+        }
+        if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[2], 1u, RLX_AGENT); break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         /* drop this CU's stale L1 lines of the neighbours' motion */
+        const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
+        const FrameDev F = Fs[g];
+        const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
+        mbk_search(F, &L, &A, x, y);
+        /* publish: stores drained, L2 written back, then the counters / queue entries */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int base = g * fl.n_mb;
+            if (x + 1 < fl.mb_w) flow_done_one(fl, base + xy + 1, item + 1u);
+            if (y + 1 < fl.mb_h) {
+                if (x >= 1) flow_done_one(fl, base + xy + fl.mb_w - 1, item + (unsigned)fl.mb_w - 1u);
+                if (x == fl.mb_w - 1) flow_done_one(fl, base + xy + fl.mb_w, item + (unsigned)fl.mb_w);
+            }
+        }
+        if (fl.fused) mbk_rca_encode(F, &L, &A, xy);
+    }
+}
+
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */
 __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__ Fs, const int *__restrict__ req, int *__restrict__ out)

@@ -95,6 +95,30 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
     }
 }
 
+/* phases B + C of one macroblock back to back (dataflow schedule): every carrier's replacement-MV
+ * cost, then the pass-1 reconstruction.  rca_mv_cost leaves the decided MVs and the cache as it found
+ * them, so one rebuild of the analysis serves all carriers and the final encode. */
+PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+{
+    int *slots = L->slots;
+    const int n = analysis_from_record(F, L, a, xy, slots);
+    if (F.rec_mb[xy].used)
+        for (int k = 0; k < n; k++) {
+            MEState *me = slot_me(L, a, slots[k]);
+            int dx = 0, dy = 0;
+            const int bx = me->mv[0], by = me->mv[1];
+            const int cost = rca_mv_cost(F, L, a, me, &dx, &dy);
+            if (PCAMV_LANE0) {
+                pcamv_mb_t *r = &F.rec_mb[xy];
+                r->mv_stego[slots[k]][0] = (int16_t)(bx + dx); r->mv_stego[slots[k]][1] = (int16_t)(by + dy);
+                r->inter_stego_cost[slots[k]] = cost;
+            }
+        }
+    update_cache(L, a);
+    mb_encode(F, L);
+    prim_store_rec(F, L);
+}
+
 PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
 {
     analysis_from_record(F, L, a, xy, L->slots);

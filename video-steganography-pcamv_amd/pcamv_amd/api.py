@@ -109,7 +109,8 @@ def param_parse(p, name, value):
 
 
 def lib_path():
-    return os.path.join(_PKG, "libpcamv_gpu.so")
+    # PCAMV_GPU_LIB: development override to A/B a differently compiled build of the same sources
+    return os.environ.get("PCAMV_GPU_LIB") or os.path.join(_PKG, "libpcamv_gpu.so")
 
 
 def build_library(force=False):
@@ -307,8 +308,13 @@ class Batch:
         if rc:
             raise PcamvError(f"batch_step failed ({rc}): {self.lib.pcamv_gpu_batch_last_error(self.b).decode()}")
 
-    def kernel_time(self, kernel="k_search_diag", reset=True):
+    def dominant_kernel(self):
+        self.lib.pcamv_gpu_batch_dominant_kernel.restype = C.c_char_p
+        return self.lib.pcamv_gpu_batch_dominant_kernel(self.b).decode()
+
+    def kernel_time(self, kernel=None, reset=True):
         ms, n = C.c_double(), C.c_int()
+        kernel = kernel or self.dominant_kernel()
         rc = self.lib.pcamv_gpu_batch_kernel_time(self.b, kernel.encode(), C.byref(ms), C.byref(n), int(reset))
         if rc:
             raise PcamvError(f"batch_kernel_time failed: {rc}")
