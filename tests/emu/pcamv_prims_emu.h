@@ -50,16 +50,6 @@ static inline int prim_cost_luma_nolog(const FrameDev &F, MBLocal *L, const uint
     const uint8_t *r = emu_qpel(F, tmp, &st, L->mb_x * 16 + xoff, L->mb_y * 16 + yoff, mx, my, w, h);
     return emu_cmp(w, h, enc + yoff * 16 + xoff, 16, r, st, satd);
 }
-static inline void prim_cost_luma_xn(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int satd, int *out)
-{
-    for (int k = 0; k < n; k++) out[k] = prim_cost_luma_nolog(F, L, enc, ip, xoff, yoff, mx[k], my[k], satd);
-    if (F.trace && L->mb_xy == F.trace_mb)
-        for (int c = 0; c < n; c++) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx[c]; t[4] = my[c]; t[5] = satd | (enc == L->recb ? 2 : 0); t[6] = out[c]; t[7] = 0; F.trace[0] = k + 1; } }
-}
-static inline int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
-{ int o[4] = {0, 0, 0, 0}, ax[4] = {mx, mx, mx, mx}, ay[4] = {my, my, my, my}; prim_cost_luma_xn(F, L, enc, ip, xoff, yoff, ax, ay, 1, satd, o); return o[0]; }
-static inline void prim_sad_fpel_xn(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int *out)
-{ int qx[4], qy[4]; for (int k = 0; k < 4; k++) { qx[k] = mx[k] * 4; qy[k] = my[k] * 4; } prim_cost_luma_xn(F, L, L->fenc, ip, xoff, yoff, qx, qy, n, 0, out); }
 static inline void emu_mc_chroma(const FrameDev &F, uint8_t *dst, int ds, int plane, int cx, int cy, int mvx, int mvy, int w, int h)
 {
     int dx = mvx & 7, dy = mvy & 7, cA = (8 - dx) * (8 - dy), cB = dx * (8 - dy), cC = (8 - dx) * dy, cD = dx * dy;
@@ -67,15 +57,29 @@ static inline void emu_mc_chroma(const FrameDev &F, uint8_t *dst, int ds, int pl
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++)
         dst[y * ds + x] = (cA * s[y * F.cstride + x] + cB * s[y * F.cstride + x + 1] + cC * s[(y + 1) * F.cstride + x] + cD * s[(y + 1) * F.cstride + x + 1] + 32) >> 6;
 }
-static inline void prim_cost_chroma_uv(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd, int *cu, int *cv)
+/* all listed candidates: pixel metric (+ MV bits) (+ chroma), costs to L->ccost, first minimum returned */
+static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int n, int flags, int mvp0, int mvp1)
 {
-    uint8_t tmp[8 * 8]; int w = pix_w_tab[ip] / 2, h = pix_h_tab[ip] / 2, r[2];
-    for (int p = 0; p < 2; p++) {
-        emu_mc_chroma(F, tmp, 8, p, L->mb_x * 8 + (xoff >> 1), L->mb_y * 8 + (yoff >> 1), mx, my, w, h);
-        r[p] = emu_cmp(w, h, enc + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
+    EvalRes r = {PCAMV_COST_MAX, -1};
+    const int satd = flags & EV_SATD;
+    for (int c = 0; c < n; c++) {
+        if (L->cxy[c] == CAND_NONE) { L->ccost[c] = PCAMV_COST_MAX; continue; }
+        const int mx = CAND_X(c), my = CAND_Y(c);
+        int cost = prim_cost_luma_nolog(F, L, enc, ip, xoff, yoff, mx, my, satd);
+        if (!(flags & EV_NOMV)) cost += F.cost_mv[mx - mvp0] + F.cost_mv[my - mvp1];
+        if (flags & EV_CHROMA) {
+            uint8_t tmp[8 * 8]; int w = pix_w_tab[ip] / 2, h = pix_h_tab[ip] / 2;
+            for (int p = 0; p < 2; p++) {
+                emu_mc_chroma(F, tmp, 8, p, L->mb_x * 8 + (xoff >> 1), L->mb_y * 8 + (yoff >> 1), mx, my, w, h);
+                int cc = emu_cmp(w, h, enc + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
+                if (flags & EV_PROBE) L->ccost[64 * (1 + p) + c] = cc; else cost += cc;
+            }
+        }
+        L->ccost[c] = cost;
+        if (cost < r.cost) { r.cost = cost; r.idx = c; }
+        if (F.trace && L->mb_xy == F.trace_mb) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = flags | (enc == L->recb ? 32 : 0); t[6] = cost; t[7] = c; F.trace[0] = k + 1; } }
     }
-    *cu = r[0]; *cv = r[1];
-    if (F.trace && L->mb_xy == F.trace_mb) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = 4 | satd | (enc == L->recb ? 2 : 0); t[6] = *cu; t[7] = *cv; F.trace[0] = k + 1; } }
+    return r;
 }
 static inline int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {

@@ -28,6 +28,8 @@
 #define PCAMV_PAD 32
 #define PCAMV_CPAD 16
 #define PCAMV_COST_MAX (1 << 28)
+#define PCAMV_COST_MV_LEN (4 * 4 * 2048 + 1)
+#define PCAMV_COST_MV_CENTRE (2 * 4 * 2048)
 #define SCAN8_0 (4 + 1 * 8)
 
 enum { PIX_16x16, PIX_16x8, PIX_8x16, PIX_8x8, PIX_8x4, PIX_4x8, PIX_4x4 };
@@ -101,7 +103,8 @@ struct MBLocal {
     uint8_t sub_part[4];
     int b_skip_mc, cbp_luma, cbp_chroma;
     int red[64];                   /* scratch for cross-lane work */
-    int candx[12], candy[12];      /* predictor candidates of the running search (always fully initialised) */
+    uint32_t cxy[64];              /* candidate list of the running evaluation: x | y << 16, quarter-pel; CAND_NONE = skip */
+    int ccost[192];                /* cost of every listed candidate ([64..191]: per-plane chroma terms of the probe kernel) */
     int mvc16[9][2];               /* candidate MVs of the 16x16 search */
     int nbc[12];                   /* neighbourhood costs of the RCA step */
     int slots[16];
@@ -110,6 +113,40 @@ struct MBLocal {
 #define NB_TOP 2
 #define NB_TOPRIGHT 4
 #define NB_TOPLEFT 8
+
+/* Candidate lists.  The search code writes up to 64 quarter-pel candidates into L->cxy and asks
+ * prim_eval_list for all their costs at once (pixel metric + MV bits [+ chroma]); the primitive
+ * leaves every cost in L->ccost and returns the smallest one with the FIRST index reaching it --
+ * exactly what the reference's sequential `if (cost < bcost)` over the same candidates in the same
+ * order produces (COST_MV / COST_MV_X4 of encoder/me.c, COST_MV_SATD, MV_SATD_FDEC_IH). */
+#define CAND_PACK(X, Y) ((uint32_t)(uint16_t)(X) | ((uint32_t)(uint16_t)(Y) << 16))
+#define CAND_NONE 0x80008000u
+#define CAND_X(c) ((int)(int16_t)(L->cxy[c] & 0xffffu))
+#define CAND_Y(c) ((int)(int16_t)(L->cxy[c] >> 16))
+#define EV_SATD 1      /* 4x4 Hadamard metric (x264 satd, 8x4-pair rounding) instead of SAD */
+#define EV_CHROMA 2    /* add the U and V cost of the co-located chroma block (partitions >= 8x8) */
+#define EV_FPEL 4      /* promise: every candidate is full-pel (single-plane fetch) */
+#define EV_NOMV 8      /* do not add the MV bit cost */
+#define EV_PROBE 16    /* chroma terms go to ccost[64 + c] (U) and ccost[128 + c] (V) instead of being added */
+struct EvalRes { int cost, idx; };
+/* lane-parallel generation of a candidate list: the body runs once per candidate index c < n (n <= 64) */
+#ifdef PCAMV_HOST_EMU
+#define FOR_CAND(c, n) for (int c = 0; c < (n); c++)
+#else
+#define FOR_CAND(c, n) for (int c = (int)(threadIdx.x & 63), c##_1 = 1; c##_1 && c < (n); c##_1 = 0)
+#endif
+
+#ifdef PCAMV_HOST_EMU
+#define PCAMV_WAVE_SYNC() do { } while (0)
+#else
+/* Lanes of the wavefront exchange data through LDS (one lane writes, another reads).  The hardware
+ * executes a wave's LDS operations in order, but to the compiler these are unsynchronised accesses of
+ * different threads which it may reorder (it does: a lane-0 store was forwarded to lane 0 while the
+ * other lanes' load of the same word was moved in front of it).  A wavefront-scope release/acquire
+ * pair emits no instruction and pins the order; every primitive begins and ends with one. */
+#define PCAMV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 struct MEState {
     int i_pixel, xoff, yoff;

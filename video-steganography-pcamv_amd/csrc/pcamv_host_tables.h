@@ -25,8 +25,6 @@ static const uint8_t pcamv_chroma_qp_tab[52] = {
     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
     29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
-#define PCAMV_COST_MV_LEN (4 * 4 * 2048 + 1)
-#define PCAMV_COST_MV_CENTRE (2 * 4 * 2048)
 
 /* lambda * (2*log2(i+1) + 0.718 + !!i) + .5 evaluated exactly as the reference's expression:
  * (float)log(x) / log(2.0) in double, times 2, plus float 0.718f, truncated to int16 */

@@ -231,16 +231,20 @@ __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__
     const int *r = req + 8 * blockIdx.x;
     L.mb_x = r[0]; L.mb_y = r[1]; L.mb_xy = r[1] * F.mb_w + r[0];
     prim_load_fenc(F, &L);
-    if (r[7] & 2) {     /* batch mode: 4 candidates around (mx,my) at once; answer = 3 of them */
-        int bx[4] = {r[5], r[5] + 1, r[5] - 2, r[5] + 3}, by[4] = {r[6], r[6] - 1, r[6] + 3, r[6] + 2}, o4[4] = {0, 0, 0, 0};
-        prim_cost_luma_xn(F, &L, L.fenc, r[2], r[3], r[4], bx, by, 4, r[7] & 1, o4);
-        if (LANE() == 0) { out[3 * blockIdx.x] = o4[1]; out[3 * blockIdx.x + 1] = o4[2]; out[3 * blockIdx.x + 2] = o4[3]; }
+    PCAMV_WAVE_SYNC();
+    const int mflag = (r[7] & 1 ? EV_SATD : 0) | EV_NOMV;
+    if (r[7] & 2) {     /* batch mode: 4 candidates around (mx,my) in one list; answer = 3 of them */
+        if (LANE() == 0) {
+            L.cxy[0] = CAND_PACK(r[5], r[6]); L.cxy[1] = CAND_PACK(r[5] + 1, r[6] - 1);
+            L.cxy[2] = CAND_PACK(r[5] - 2, r[6] + 3); L.cxy[3] = CAND_PACK(r[5] + 3, r[6] + 2);
+        }
+        prim_eval_list(F, &L, L.fenc, r[2], r[3], r[4], 4, mflag, 0, 0);
+        if (LANE() == 0) { out[3 * blockIdx.x] = L.ccost[1]; out[3 * blockIdx.x + 1] = L.ccost[2]; out[3 * blockIdx.x + 2] = L.ccost[3]; }
         return;
     }
-    int luma = prim_cost_luma(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7]);
-    int cu = 0, cv = 0;
-    if (r[2] <= PIX_8x8) prim_cost_chroma_uv(F, &L, L.fenc, r[2], r[3], r[4], r[5], r[6], r[7], &cu, &cv);
-    if (LANE() == 0) { out[3 * blockIdx.x] = luma; out[3 * blockIdx.x + 1] = cu; out[3 * blockIdx.x + 2] = cv; }
+    if (LANE() == 0) { L.cxy[0] = CAND_PACK(r[5], r[6]); L.ccost[64] = 0; L.ccost[128] = 0; }
+    prim_eval_list(F, &L, L.fenc, r[2], r[3], r[4], 1, mflag | EV_CHROMA | EV_PROBE, 0, 0);
+    if (LANE() == 0) { out[3 * blockIdx.x] = L.ccost[0]; out[3 * blockIdx.x + 1] = L.ccost[64]; out[3 * blockIdx.x + 2] = L.ccost[128]; }
 }
 
 /* ------------------------------------------------------------------ embedding stage */

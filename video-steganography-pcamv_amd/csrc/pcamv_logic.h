@@ -168,149 +168,125 @@ PCAMV_CONST int hex4_tab[16][2] = {{-4, 2}, {-4, 1}, {-4, 0}, {-4, -1}, {-4, -2}
 PCAMV_CONST int range_mul_tab[4][4] = {{3, 3, 4, 4}, {3, 4, 4, 4}, {4, 4, 4, 5}, {4, 4, 5, 6}};
 PCAMV_CONST int size_shift_tab[7] = {0, 1, 1, 2, 3, 3, 4};
 
-struct SearchCtx {
-    const FrameDev *F; MBLocal *L; MEState *me;
-    int bmx, bmy, bcost;
-};
 #define MVCOSTX(v) ((int)F.cost_mv[(v) - me->mvp[0]])
 #define MVCOSTY(v) ((int)F.cost_mv[(v) - me->mvp[1]])
 
-/* up to 4 full-pel candidates at once; costs include the MV bits; best updated in order (strict <) */
-PCAMV_DEV void fpel_try(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
-                        const int *mx, const int *my, int n, int *costs_out)
+PCAMV_DEV EvalRes eval_cands(const FrameDev &F, MBLocal *L, MEState *me, const uint8_t *enc, int n, int flags)
 {
-    int c[4] = {0, 0, 0, 0};
-    prim_sad_fpel_xn(F, L, me->i_pixel, me->xoff, me->yoff, mx, my, n, c);
-    for (int k = 0; k < n; k++) {
-        c[k] += MVCOSTX(mx[k] * 4) + MVCOSTY(my[k] * 4);
-        if (costs_out) costs_out[k] = c[k];
-        else if (c[k] < bcost) { bcost = c[k]; bmx = mx[k]; bmy = my[k]; }
-    }
+    return prim_eval_list(F, L, enc, me->i_pixel, me->xoff, me->yoff, n, flags, me->mvp[0], me->mvp[1]);
 }
-#define TRY1(X, Y) { int tx_[4] = {X, X, X, X}, ty_[4] = {Y, Y, Y, Y}; fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 1, 0); }
+/* the n listed full-pel candidates folded into the running best, in list order (strict <) */
+PCAMV_DEV int fpel_fold(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int n)
+{
+    EvalRes r = eval_cands(F, L, me, L->fenc, n, EV_FPEL);
+    if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx) >> 2; bmy = CAND_Y(r.idx) >> 2; return r.idx; }
+    return -1;
+}
+#define FSET(c, X, Y) (L->cxy[c] = CAND_PACK((X) * 4, (Y) * 4))
 #define TRY4(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1) { \
-        int tx_[4] = {(ox) + (a0), (ox) + (b0), (ox) + (c0), (ox) + (d0)}, ty_[4] = {(oy) + (a1), (oy) + (b1), (oy) + (c1), (oy) + (d1)}; \
-        fpel_try(F, L, me, bmx, bmy, bcost, tx_, ty_, 4, 0); }
+        FSET(0, (ox) + (a0), (oy) + (a1)); FSET(1, (ox) + (b0), (oy) + (b1)); FSET(2, (ox) + (c0), (oy) + (c1)); FSET(3, (ox) + (d0), (oy) + (d1)); \
+        fpel_fold(F, L, me, bmx, bmy, bcost, 4); }
+#define TRY8(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1, e0, e1, f0, f1, g0, g1, h0, h1) { \
+        FSET(0, (ox) + (a0), (oy) + (a1)); FSET(1, (ox) + (b0), (oy) + (b1)); FSET(2, (ox) + (c0), (oy) + (c1)); FSET(3, (ox) + (d0), (oy) + (d1)); \
+        FSET(4, (ox) + (e0), (oy) + (e1)); FSET(5, (ox) + (f0), (oy) + (f1)); FSET(6, (ox) + (g0), (oy) + (g1)); FSET(7, (ox) + (h0), (oy) + (h1)); \
+        fpel_fold(F, L, me, bmx, bmy, bcost, 8); }
 #define CHECK_MVRANGE(mx, my) ((mx) >= mv_x_min && (mx) <= mv_x_max && (my) >= mv_y_min && (my) <= mv_y_max)
-
-/* qpel-precision cost of one candidate with the conditional chroma terms of COST_MV_SATD */
-PCAMV_DEV int qpel_cost_with_chroma(const FrameDev &F, MBLocal *L, MEState *me, int luma_cost, int mx, int my, int bcost, int b_chroma_me)
-{
-    int cost = luma_cost;
-    if (b_chroma_me && cost < bcost) {
-        int cu, cv;
-        prim_cost_chroma_uv(F, L, L->fenc, me->i_pixel, me->xoff, me->yoff, mx, my, F.subme > 1, &cu, &cv);
-        cost += cu;
-        if (cost < bcost) cost += cv;
-    }
-    return cost;
-}
 
 PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpel_iters, int qpel_iters, int b_refine_qpel)
 {
     const int ip = me->i_pixel;
     const int b_chroma_me = F.b_chroma_me && ip <= PIX_8x8;
-    const int satd = F.subme > 1;
+    const int qflags = (F.subme > 1 ? EV_SATD : 0) | (b_chroma_me ? EV_CHROMA : 0);
     int bmx = me->mv[0], bmy = me->mv[1], bcost = me->cost, odir = -1, bdir;
     if (hpel_iters && F.subme < 3) {
         int mx = clip3i(me->mvp[0], L->mv_min_spel[0], L->mv_max_spel[0]);
         int my = clip3i(me->mvp[1], L->mv_min_spel[1], L->mv_max_spel[1]);
         if ((mx - bmx) | (my - bmy)) {
-            int c = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, mx, my, 0) + MVCOSTX(mx) + MVCOSTY(my);
-            if (c < bcost) { bcost = c; bmx = mx; bmy = my; }
+            L->cxy[0] = CAND_PACK(mx, my);
+            EvalRes r = eval_cands(F, L, me, L->fenc, 1, 0);
+            if (r.cost < bcost) { bcost = r.cost; bmx = mx; bmy = my; }
         }
     }
     for (int i = hpel_iters; i > 0; i--) {
-        int omx = bmx, omy = bmy, c[4] = {0, 0, 0, 0};
-        int cx[4] = {omx, omx, omx - 2, omx + 2}, cy[4] = {omy - 2, omy + 2, omy, omy};
-        prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, 0, c);
-        c[0] += MVCOSTX(omx) + MVCOSTY(omy - 2); if (c[0] < bcost) { bcost = c[0]; bmy = omy - 2; }
-        c[1] += MVCOSTX(omx) + MVCOSTY(omy + 2); if (c[1] < bcost) { bcost = c[1]; bmy = omy + 2; }
-        c[2] += MVCOSTX(omx - 2) + MVCOSTY(omy); if (c[2] < bcost) { bcost = c[2]; bmx = omx - 2; bmy = omy; }
-        c[3] += MVCOSTX(omx + 2) + MVCOSTY(omy); if (c[3] < bcost) { bcost = c[3]; bmx = omx + 2; bmy = omy; }
+        int omx = bmx, omy = bmy;
+        L->cxy[0] = CAND_PACK(omx, omy - 2); L->cxy[1] = CAND_PACK(omx, omy + 2);
+        L->cxy[2] = CAND_PACK(omx - 2, omy); L->cxy[3] = CAND_PACK(omx + 2, omy);
+        EvalRes r = eval_cands(F, L, me, L->fenc, 4, 0);
+        if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx); bmy = CAND_Y(r.idx); }
         if (bmx == omx && bmy == omy) break;
     }
     if (!b_refine_qpel) {
+        /* COST_MV_SATD of the half-pel result; the conditional chroma terms of the reference only skip
+         * work for candidates that cannot win, so the full cost decides identically */
         if (bmy > L->mv_max_spel[1]) bmy = L->mv_max_spel[1];
-        bcost = PCAMV_COST_MAX;
-        int lc = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, bmx, bmy, satd) + MVCOSTX(bmx) + MVCOSTY(bmy);
-        int c = qpel_cost_with_chroma(F, L, me, lc, bmx, bmy, bcost, b_chroma_me);
-        if (c < bcost) bcost = c;
+        L->cxy[0] = CAND_PACK(bmx, bmy);
+        bcost = eval_cands(F, L, me, L->fenc, 1, qflags).cost;
     }
     bdir = -1;
     for (int i = qpel_iters; i > 0; i--) {
         odir = bdir;
-        int omx = bmx, omy = bmy, lc[4] = {0, 0, 0, 0};
-        int cx[4] = {omx, omx, omx - 1, omx + 1}, cy[4] = {omy - 1, omy + 1, omy, omy};
-        prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, cx, cy, 4, satd, lc);
-        for (int k = 0; k < 4; k++) {
-            if (!(b_refine_qpel || (k ^ 1) != odir)) continue;
-            int l = lc[k] + MVCOSTX(cx[k]) + MVCOSTY(cy[k]);
-            int c = qpel_cost_with_chroma(F, L, me, l, cx[k], cy[k], bcost, b_chroma_me);
-            if (c < bcost) { bcost = c; bmx = cx[k]; bmy = cy[k]; bdir = k; }
-        }
+        int omx = bmx, omy = bmy;
+        L->cxy[0] = CAND_PACK(omx, omy - 1); L->cxy[1] = CAND_PACK(omx, omy + 1);
+        L->cxy[2] = CAND_PACK(omx - 1, omy); L->cxy[3] = CAND_PACK(omx + 1, omy);
+        if (!b_refine_qpel && odir >= 0) L->cxy[odir ^ 1] = CAND_NONE;      /* never step straight back */
+        EvalRes r = eval_cands(F, L, me, L->fenc, 4, qflags);
+        if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx); bmy = CAND_Y(r.idx); bdir = r.idx; }
         if (bmx == omx && bmy == omy) break;
     }
     if (bmy > L->mv_max_spel[1]) {
         bmy = L->mv_max_spel[1];
-        bcost = PCAMV_COST_MAX;
-        int lc = prim_cost_luma(F, L, L->fenc, ip, me->xoff, me->yoff, bmx, bmy, satd) + MVCOSTX(bmx) + MVCOSTY(bmy);
-        int c = qpel_cost_with_chroma(F, L, me, lc, bmx, bmy, bcost, b_chroma_me);
-        if (c < bcost) bcost = c;
+        L->cxy[0] = CAND_PACK(bmx, bmy);
+        bcost = eval_cands(F, L, me, L->fenc, 1, qflags).cost;
     }
     me->cost = bcost; me->mv[0] = bmx; me->mv[1] = bmy;
     me->cost_mv = MVCOSTX(bmx) + MVCOSTY(bmy);
 }
 
+/* the two arms of the UMH cross (me.c:331-357 CROSS): +i, -i for i = start, start+2, .. < max, first
+ * along x then along y; candidates beyond the search window are skipped */
 PCAMV_DEV void cross_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
                             int omx, int omy, int start, int x_max, int y_max,
                             int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
 {
-    int i = start;
-    if (x_max <= imin(mv_x_max - omx, omx - mv_x_min))
-        for (; i < x_max - 2; i += 4) TRY4(omx, omy, i, 0, -i, 0, i + 2, 0, -i - 2, 0);
-    for (; i < x_max; i += 2) {
-        if (omx + i <= mv_x_max) TRY1(omx + i, omy);
-        if (omx - i >= mv_x_min) TRY1(omx - i, omy);
-    }
-    i = start;
-    if (y_max <= imin(mv_y_max - omy, omy - mv_y_min))
-        for (; i < y_max - 2; i += 4) TRY4(omx, omy, 0, i, 0, -i, 0, i + 2, 0, -i - 2);
-    for (; i < y_max; i += 2) {
-        if (omy + i <= mv_y_max) TRY1(omx, omy + i);
-        if (omy - i >= mv_y_min) TRY1(omx, omy - i);
+    const int nx = x_max > start ? (x_max - start + 1) >> 1 : 0;
+    const int ny = y_max > start ? (y_max - start + 1) >> 1 : 0;
+    const int total = 2 * (nx + ny);
+    for (int base = 0; base < total; base += 64) {
+        const int n = imin(64, total - base);
+        FOR_CAND(c, n) {
+            int g = base + c, isy = g >= 2 * nx, hh = isy ? g - 2 * nx : g;
+            int i = start + 2 * (hh >> 1), neg = hh & 1, d = neg ? -i : i;
+            int x = isy ? omx : omx + d, y = isy ? omy + d : omy;
+            int ok = isy ? (neg ? y >= mv_y_min : y <= mv_y_max) : (neg ? x >= mv_x_min : x <= mv_x_max);
+            L->cxy[c] = ok ? CAND_PACK(x * 4, y * 4) : CAND_NONE;
+        }
+        fpel_fold(F, L, me, bmx, bmy, bcost, n);
     }
 }
 
 PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int i_me_range,
                           int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
 {
-    int costs[6], dir = -2;
+    int dir = -2;
+    FOR_CAND(c, 6) L->cxy[c] = CAND_PACK((bmx + hex2_tab[c + 1][0]) * 4, (bmy + hex2_tab[c + 1][1]) * 4);
     {
-        int tx[4] = {bmx - 2, bmx - 1, bmx + 1, bmx + 2}, ty[4] = {bmy, bmy + 2, bmy + 2, bmy};
-        int ux[4] = {bmx + 1, bmx - 1, bmx, bmx}, uy[4] = {bmy - 2, bmy - 2, bmy, bmy};
-        fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 4, costs);
-        fpel_try(F, L, me, bmx, bmy, bcost, ux, uy, 2, costs + 4);
+        EvalRes r = eval_cands(F, L, me, L->fenc, 6, EV_FPEL);
+        if (r.cost < bcost) { bcost = r.cost; dir = r.idx; }
     }
-    for (int i = 0; i < 6; i++) if (costs[i] < bcost) { bcost = costs[i]; dir = i; }
     if (dir != -2) {
         bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
         for (int i = 1; i < i_me_range / 2 && CHECK_MVRANGE(bmx, bmy); i++) {
             const int odir = mod6m1_tab[dir + 1];
-            int tx[4] = {bmx + hex2_tab[odir][0], bmx + hex2_tab[odir + 1][0], bmx + hex2_tab[odir + 2][0], bmx};
-            int ty[4] = {bmy + hex2_tab[odir][1], bmy + hex2_tab[odir + 1][1], bmy + hex2_tab[odir + 2][1], bmy};
-            fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 3, costs);
+            FOR_CAND(c, 3) L->cxy[c] = CAND_PACK((bmx + hex2_tab[odir + c][0]) * 4, (bmy + hex2_tab[odir + c][1]) * 4);
+            EvalRes r = eval_cands(F, L, me, L->fenc, 3, EV_FPEL);
             dir = -2;
-            if (costs[0] < bcost) { bcost = costs[0]; dir = odir - 1; }
-            if (costs[1] < bcost) { bcost = costs[1]; dir = odir; }
-            if (costs[2] < bcost) { bcost = costs[2]; dir = odir + 1; }
+            if (r.cost < bcost) { bcost = r.cost; dir = odir - 1 + r.idx; }
             if (dir == -2) break;
             bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
         }
     }
     int omx = bmx, omy = bmy;
-    TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0);
-    TRY4(omx, omy, -1, -1, -1, 1, 1, -1, 1, 1);
+    TRY8(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0, -1, -1, -1, 1, 1, -1, 1, 1);
 }
 
 PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc)
@@ -326,41 +302,34 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     bcost = PCAMV_COST_MAX;
 
     if (F.subme >= 3) {
-        /* qpel-precision test of the predictor and the candidates (plain SAD) */
-        int n = 0, sx = bmx, sy = bmy;
-        for (int i = 0; i < 12; i++) { L->candx[i] = bmx; L->candy[i] = bmy; }
-        n = 1;
+        /* quarter-pel test of the predictor and the candidates (plain SAD), me.c:202-230 */
+        int n = 1, sx = bmx, sy = bmy;
+        L->cxy[0] = CAND_PACK(bmx, bmy);
         for (int i = 0; i < i_mvc; i++)
             if ((mvc[i][0] | mvc[i][1]) && ((sx - mvc[i][0]) | (sy - mvc[i][1]))) {
-                L->candx[n] = clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4);
-                L->candy[n] = clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4);
+                L->cxy[n] = CAND_PACK(clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4), clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4));
                 n++;
             }
-        for (int b = 0; b < n; b += 4) {
-            int c[4] = {0, 0, 0, 0}, nn = imin(4, n - b);
-            int qx[4] = {L->candx[b], L->candx[b + 1], L->candx[b + 2], L->candx[b + 3]};
-            int qy[4] = {L->candy[b], L->candy[b + 1], L->candy[b + 2], L->candy[b + 3]};
-            prim_cost_luma_xn(F, L, L->fenc, ip, me->xoff, me->yoff, qx, qy, nn, 0, c);
-            for (int k = 0; k < 4; k++) {
-                if (k >= nn) break;
-                int cc = c[k] + MVCOSTX(qx[k]) + MVCOSTY(qy[k]);
-                if (cc < bpred_cost) { bpred_cost = cc; bpred_mx = qx[k]; bpred_my = qy[k]; }
-            }
-        }
+        EvalRes r = eval_cands(F, L, me, L->fenc, n, 0);
+        bpred_cost = r.cost; bpred_mx = CAND_X(r.idx); bpred_my = CAND_Y(r.idx);
         bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
-        TRY1(bmx, bmy);
+        FSET(0, bmx, bmy); FSET(1, 0, 0);
+        fpel_fold(F, L, me, bmx, bmy, bcost, 2);
     } else {
-        TRY1(pmx, pmy);
-        bcost -= MVCOSTX(pmx * 4) + MVCOSTY(pmy * 4);
+        /* full-pel test: the predictor (its MV bits not charged), then the candidates, then (0,0).
+         * Candidates equal to the running best are listed too: their cost cannot be smaller. */
+        int n = 1;
+        FSET(0, pmx, pmy);
         for (int i = 0; i < i_mvc; i++) {
             int mx = (mvc[i][0] + 2) >> 2, my = (mvc[i][1] + 2) >> 2;
-            if ((mx | my) && ((mx - bmx) | (my - bmy))) {
-                mx = clip3i(mx, mv_x_min, mv_x_max); my = clip3i(my, mv_y_min, mv_y_max);
-                TRY1(mx, my);
-            }
+            if (mx | my) { FSET(n, clip3i(mx, mv_x_min, mv_x_max), clip3i(my, mv_y_min, mv_y_max)); n++; }
         }
+        FSET(n, 0, 0); n++;
+        eval_cands(F, L, me, L->fenc, n, EV_FPEL);
+        bcost = L->ccost[0] - (MVCOSTX(pmx * 4) + MVCOSTY(pmy * 4)); bmx = pmx; bmy = pmy;
+        for (int k = 1; k < n; k++)
+            if (L->ccost[k] < bcost) { bcost = L->ccost[k]; bmx = CAND_X(k) >> 2; bmy = CAND_Y(k) >> 2; }
     }
-    TRY1(0, 0);
 
     if (F.me_method == PCAMV_ME_DIA) {
         int i = 0;
@@ -376,22 +345,20 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
 #define SAD_THRESH(v) (bcost < ((v) >> size_shift_tab[ip]))
         ucost1 = bcost;
-        TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0);
-        if (pmx | pmy) TRY4(0, 0, 0, -1, 0, 1, -1, 0, 1, 0);
+        if (pmx | pmy) { TRY8(0, 0, pmx, pmy - 1, pmx, pmy + 1, pmx - 1, pmy, pmx + 1, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
+        else { TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
         if (ip != PIX_4x4) {
             ucost2 = bcost;
             if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) { omx = bmx; omy = bmy; TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0); }
             if (bcost == ucost2) cross_start = 3;
             omx = bmx; omy = bmy;
             if (bcost == ucost2 && SAD_THRESH(2000)) {
-                TRY4(omx, omy, 0, -2, -1, -1, 1, -1, -2, 0);
-                TRY4(omx, omy, 2, 0, -1, 1, 1, 1, 0, 2);
+                TRY8(omx, omy, 0, -2, -1, -1, 1, -1, -2, 0, 2, 0, -1, 1, 1, 1, 0, 2);
                 if (bcost == ucost1 && SAD_THRESH(500)) { done = 1; do_hex = 0; }
                 else if (bcost == ucost2) {
                     int range = (i_me_range >> 1) | 1;
                     cross_search(F, L, me, bmx, bmy, bcost, omx, omy, 3, range, range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
-                    TRY4(omx, omy, -1, -2, 1, -2, -2, -1, 2, -1);
-                    TRY4(omx, omy, -2, 1, 2, 1, -1, 2, 1, 2);
+                    TRY8(omx, omy, -1, -2, 1, -2, -2, -1, 2, -1, -2, 1, 2, 1, -1, 2, 1, 2);
                     if (bcost == ucost2) { done = 1; do_hex = 0; }
                     cross_start = range + 2;
                 }
@@ -413,22 +380,18 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                 }
                 cross_search(F, L, me, bmx, bmy, bcost, omx, omy, cross_start, i_me_range, i_me_range / 2, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
                 TRY4(omx, omy, -2, -2, -2, 2, 2, -2, 2, 2);
+                /* 16-point hexagons at radii 4, 8, .. around the (fixed) cross result, me.c:404-457 */
                 omx = bmx; omy = bmy;
-                int i = 1;
-                do {
-                    if (4 * i > imin(imin(mv_x_max - omx, omx - mv_x_min), imin(mv_y_max - omy, omy - mv_y_min))) {
-                        for (int j = 0; j < 16; j++) {
-                            int mx = omx + hex4_tab[j][0] * i, my = omy + hex4_tab[j][1] * i;
-                            if (CHECK_MVRANGE(mx, my)) TRY1(mx, my);
-                        }
-                    } else {
-                        for (int j = 0; j < 16; j += 4) {
-                            int tx[4], ty[4];
-                            for (int k = 0; k < 4; k++) { tx[k] = omx + hex4_tab[j + k][0] * i; ty[k] = omy + hex4_tab[j + k][1] * i; }
-                            fpel_try(F, L, me, bmx, bmy, bcost, tx, ty, 4, 0);
-                        }
+                const int total = 16 * imax(1, i_me_range / 4);
+                for (int base = 0; base < total; base += 64) {
+                    const int n = imin(64, total - base);
+                    FOR_CAND(c, n) {
+                        int g = base + c, i = 1 + (g >> 4), j = g & 15;
+                        int mx = omx + hex4_tab[j][0] * i, my = omy + hex4_tab[j][1] * i;
+                        L->cxy[c] = CHECK_MVRANGE(mx, my) ? CAND_PACK(mx * 4, my * 4) : CAND_NONE;
                     }
-                } while (++i <= i_me_range / 4);
+                    fpel_fold(F, L, me, bmx, bmy, bcost, n);
+                }
                 if (!(bmy <= mv_y_max)) do_hex = 0;
             }
         }
@@ -680,37 +643,20 @@ PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8
     if (pixel == PIX_4x4) a->cost4x4[i8] = cost; else if (pixel == PIX_8x4) a->cost8x4[i8] = cost; else a->cost4x8[i8] = cost;
 }
 
-/* SATD of the reconstruction against the reference at (mx,my): MV_SATD_FDEC_IH */
-PCAMV_DEV int mv_satd_rec(const FrameDev &F, MBLocal *L, MEState *me, int luma_cost, int mx, int my)
-{
-    int cost = luma_cost + MVCOSTX(mx) + MVCOSTY(my);
-    if (F.b_chroma_me && me->i_pixel <= PIX_8x8) {
-        int cu, cv;
-        prim_cost_chroma_uv(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, mx, my, F.subme > 1, &cu, &cv);
-        cost += cu + cv;
-    }
-    return cost;
-}
 PCAMV_CONST signed char d_mv_tab[12][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-2, 1}, {-1, 2}, {1, 2}, {2, 1}, {2, -1}, {1, -2}, {-1, -2}, {-2, -1}};
 PCAMV_CONST signed char d_nb_tab[9][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {0, 0}};
 
-/* nine neighbourhood costs around (cx,cy) on the current reconstruction; returns min, last in *last */
+/* nine neighbourhood costs around (cx,cy) on the current reconstruction (MV_SATD_FDEC_IH: metric of
+ * the reconstructed block against the reference at the candidate MV + MV bits + chroma for
+ * partitions >= 8x8), one list; returns the minimum, the centre's cost in *last */
 PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, int cx, int cy, int nb_cost, int *last)
 {
-    int mn = PCAMV_COST_MAX, c = 0;
-    for (int b = 0; b < 9; b += 4) {
-        int qx[4], qy[4], lc[4] = {0, 0, 0, 0}, nn = imin(4, 9 - b);
-        for (int k = 0; k < 4; k++) { int kk = imin(b + k, 8); qx[k] = cx + d_nb_tab[kk][0]; qy[k] = cy + d_nb_tab[kk][1]; }
-        prim_cost_luma_xn(F, L, L->recb, me->i_pixel, me->xoff, me->yoff, qx, qy, nn, F.subme > 1, lc);
-        for (int k = 0; k < 4; k++) {
-            if (k >= nn) break;
-            c = mv_satd_rec(F, L, me, lc[k], qx[k], qy[k]);
-            if (nb_cost) L->nbc[b + k] = c;
-            if (c < mn) mn = c;
-        }
-    }
-    *last = c;
-    return mn;
+    const int flags = (F.subme > 1 ? EV_SATD : 0) | ((F.b_chroma_me && me->i_pixel <= PIX_8x8) ? EV_CHROMA : 0);
+    FOR_CAND(c, 9) L->cxy[c] = CAND_PACK(cx + d_nb_tab[c][0], cy + d_nb_tab[c][1]);
+    EvalRes r = eval_cands(F, L, me, L->recb, 9, flags);
+    if (nb_cost) { FOR_CAND(c, 9) L->nbc[c] = L->ccost[c]; PCAMV_WAVE_SYNC(); }
+    *last = L->ccost[8];
+    return r.cost;
 }
 
 PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *me, int *m_x, int *m_y)

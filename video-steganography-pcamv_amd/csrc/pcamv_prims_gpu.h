@@ -19,7 +19,6 @@
 #include "pcamv_common.h"
 
 #define LANE() ((int)(threadIdx.x & 63))
-
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t lds4(const uint8_t *p) { return *(const uint32_t *)p; }
 __device__ __forceinline__ void sts4(uint8_t *p, uint32_t v) { *(uint32_t *)p = v; }
@@ -82,57 +81,6 @@ __device__ __forceinline__ int hadamard4x4_abs(const uint32_t e[4], const uint32
     return s;
 }
 
-/* n <= 4 quarter-pel candidates of block (ip at xoff,yoff) against source rows in enc (LDS, stride 16) */
-__device__ __forceinline__ void prim_cost_luma_xn(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff,
-                                                  const int *mx, const int *my, int n, int satd, int *out)
-{
-    const int w4 = pix_w_tab[ip] >> 2, nblk = w4 * (pix_h_tab[ip] >> 2);
-    const int lane = LANE();
-    const int cand = lane / nblk, blk = lane - cand * nblk;
-    const int bx = blk % w4, by = blk / w4;
-    const bool act = cand < n && cand < 4;
-    int v = 0;
-    if (act) {
-        int mvx = cand == 0 ? mx[0] : cand == 1 ? mx[1] : cand == 2 ? mx[2] : mx[3];
-        int mvy = cand == 0 ? my[0] : cand == 1 ? my[1] : cand == 2 ? my[2] : my[3];
-        int px = xoff + 4 * bx, py = yoff + 4 * by;
-        QpelPos q = qpel_pos(F, L->mb_x * 16 + px, L->mb_y * 16 + py, mvx, mvy);
-        uint32_t e[4], r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { r[k] = qpel_row(q, F, k); e[k] = lds4(enc + (py + k) * 16 + px); }
-        if (satd) v = hadamard4x4_abs(e, r);
-        else {
-            uint32_t s = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(e[k], r[k], s);
-            v = (int)s;
-        }
-    }
-    if (satd) {
-        if (w4 >= 2) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }   /* 8x4 units: two 4x4 sums halved together */
-        else v >>= 1;
-    }
-    v = group_sum(v, nblk);
-    out[0] = __builtin_amdgcn_readlane(v, 0);
-    if (n > 1) out[1] = __builtin_amdgcn_readlane(v, nblk);
-    if (n > 2) out[2] = __builtin_amdgcn_readlane(v, 2 * nblk);
-    if (n > 3) out[3] = __builtin_amdgcn_readlane(v, 3 * nblk);
-    if (F.trace && L->mb_xy == F.trace_mb && lane == 0)
-        for (int c = 0; c < n; c++) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx[c]; t[4] = my[c]; t[5] = satd | (enc == L->recb ? 2 : 0); t[6] = out[c]; t[7] = 0; F.trace[0] = k + 1; } }
-}
-__device__ __forceinline__ int prim_cost_luma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
-{
-    int o[4] = {0, 0, 0, 0}, ax[4] = {mx, mx, mx, mx}, ay[4] = {my, my, my, my};
-    prim_cost_luma_xn(F, L, enc, ip, xoff, yoff, ax, ay, 1, satd, o);
-    return o[0];
-}
-__device__ __forceinline__ void prim_sad_fpel_xn(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, const int *mx, const int *my, int n, int *out)
-{
-    int qx[4], qy[4];      /* callers always pass 4 initialised entries */
-    for (int k = 0; k < 4; k++) { qx[k] = mx[k] * 4; qy[k] = my[k] * 4; }
-    prim_cost_luma_xn(F, L, L->fenc, ip, xoff, yoff, qx, qy, n, 0, out);
-}
-
 /* 4 chroma pixels of mc_chroma (mc.c:246-277) at chroma-plane position (cx,cy) */
 __device__ __forceinline__ uint32_t chroma_row4(const FrameDev &F, int plane, int cx, int cy, int mvx, int mvy)
 {
@@ -149,44 +97,131 @@ __device__ __forceinline__ uint32_t chroma_row4(const FrameDev &F, int plane, in
     }
     return o;
 }
-/* chroma cost of both planes for the block co-located with luma block (ip,xoff,yoff): lanes 0..nb-1 = U, nb..2nb-1 = V */
-__device__ __forceinline__ void prim_cost_chroma_uv(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff,
-                                                    int mx, int my, int satd, int *cu, int *cv)
+
+PCAMV_CONST unsigned char lg_nblk_tab[7] = {4, 3, 3, 2, 1, 1, 0};   /* log2 of the 4x4 blocks per partition */
+PCAMV_CONST unsigned char lg_w4_tab[7] = {2, 2, 1, 1, 1, 0, 0};     /* log2 of the partition width in 4x4 blocks */
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_min_i32(int v)
 {
-    const int cw4 = pix_w_tab[ip] >> 3, nb = cw4 * (pix_h_tab[ip] >> 3);     /* chroma 4x4 blocks: 4,2,2,1 */
+    v = imin(v, dpp_qp1(v)); v = imin(v, dpp_qp2(v)); v = imin(v, dpp_hmir(v)); v = imin(v, dpp_mir(v));
+    return imin(imin(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                imin(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+/* Costs of the n <= 64 candidates listed in L->cxy for the block (ip at xoff,yoff) against the source
+ * rows in enc (LDS: L->fenc or L->recb).
+ *   luma:   lane = slot * nblk + blk, 64/nblk candidates per pass, passes back to back so that the
+ *           loads of all of them are in flight together; each lane fetches its 4x4 reference pixels
+ *           (one or two planes, v_lerp_u8), SAD (v_sad_u8) or Hadamard, DPP butterfly over the nblk
+ *           lanes, MV bits looked up per lane, the group's first lane stores the total to ccost[c];
+ *   chroma: (partitions >= 8x8) lane = slot * 2nb + plane * nb + blk, both planes of 128/nblk
+ *           candidates per pass, group totals added to ccost[c] with an LDS atomic;
+ *   result: lane c reads ccost[c], key = cost << 6 | c, wave minimum -> smallest cost, first index. */
+__device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip_, int xoff_, int yoff_,
+                                                  int n_, int flags_, int mvp0_, int mvp1_)
+{
+    const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), n = rfl(n_), flags = rfl(flags_), mvp0 = rfl(mvp0_), mvp1 = rfl(mvp1_);
     const int lane = LANE();
-    const int plane = lane / nb, blk = lane - plane * nb;
-    const int bx = blk % cw4, by = blk / cw4;
-    int v = 0;
-    if (plane < 2) {
-        int px = (xoff >> 1) + 4 * bx, py = (yoff >> 1) + 4 * by;
-        uint32_t e[4], r[4];
+    const int lgn = lg_nblk_tab[ip], lgw = lg_w4_tab[ip], nblk = 1 << lgn;
+    const int satd = flags & EV_SATD;
+    const int16_t *cost_tab = F.cost_mv - PCAMV_COST_MV_CENTRE;
+    PCAMV_WAVE_SYNC();
+    {
+        const int slot = lane >> lgn, blk = lane & (nblk - 1);
+        const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
+        uint32_t e[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            r[k] = chroma_row4(F, plane, L->mb_x * 8 + px, L->mb_y * 8 + py + k, mx, my);
-            e[k] = lds4(enc + 256 + (py + k) * 16 + plane * 8 + px);
+        for (int k = 0; k < 4; k++) e[k] = lds4(enc + (py + k) * 16 + px);
+        const int gx = L->mb_x * 16 + px, gy = L->mb_y * 16 + py;
+        const int cpp = 64 >> lgn;
+        for (int p0 = 0; p0 < n; p0 += cpp) {
+            const int c = p0 + slot;
+            const uint32_t xy = L->cxy[c < n ? c : 0];
+            const bool act = c < n && xy != CAND_NONE;
+            const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
+            uint32_t r[4];
+            if (flags & EV_FPEL) {
+                const uint8_t *a = F.luma[0] + (ptrdiff_t)(gy + (mvy >> 2)) * F.stride + gx + (mvx >> 2);
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = ld4u(a + (ptrdiff_t)k * F.stride);
+            } else {
+                QpelPos q = qpel_pos(F, gx, gy, mvx, mvy);
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = qpel_row(q, F, k);
+            }
+            int v;
+            if (satd) {
+                v = hadamard4x4_abs(e, r);
+                if (lgw >= 1) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }   /* 8x4 units: two 4x4 sums halved together */
+                else v >>= 1;
+            } else {
+                uint32_t sa = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa);
+                v = (int)sa;
+            }
+            v = group_sum(v, nblk);
+            if (!(flags & EV_NOMV)) v += (int)cost_tab[(unsigned)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)] + (int)cost_tab[(unsigned)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)];
+            if (blk == 0 && c < n) L->ccost[c] = act ? v : PCAMV_COST_MAX;
         }
-        if (satd) v = hadamard4x4_abs(e, r);
-        else { uint32_t s = 0; for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(e[k], r[k], s); v = (int)s; }
     }
-    if (satd) {
-        if (cw4 >= 2) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }
-        else v >>= 1;
+    PCAMV_WAVE_SYNC();
+    if ((flags & EV_CHROMA) && ip <= PIX_8x8) {
+        const int lgnb = lgn - 2, nb = 1 << lgnb, lgcw = lgw - 1;          /* chroma 4x4 blocks per plane: 4,2,2,1 */
+        const int slot = lane >> (lgnb + 1), plane = (lane >> lgnb) & 1, blk = lane & (nb - 1);
+        const int px = (xoff >> 1) + 4 * (blk & ((1 << lgcw) - 1)), py = (yoff >> 1) + 4 * (blk >> lgcw);
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = lds4(enc + 256 + (py + k) * 16 + plane * 8 + px);
+        const int cpp = 64 >> (lgnb + 1);
+        for (int p0 = 0; p0 < n; p0 += cpp) {
+            const int c = p0 + slot;
+            const uint32_t xy = L->cxy[c < n ? c : 0];
+            const bool act = c < n && xy != CAND_NONE;
+            const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = chroma_row4(F, plane, L->mb_x * 8 + px, L->mb_y * 8 + py + k, mvx, mvy);
+            int v;
+            if (satd) {
+                v = hadamard4x4_abs(e, r);
+                if (lgcw >= 1) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }
+                else v >>= 1;
+            } else {
+                uint32_t sa = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa);
+                v = (int)sa;
+            }
+            v = group_sum(v, nb);
+            if (blk == 0 && act) {
+                if (flags & EV_PROBE) L->ccost[64 * (1 + plane) + c] = v;
+                else atomicAdd(&L->ccost[c], v);
+            }
+        }
     }
-    v = group_sum(v, nb);
-    *cu = __builtin_amdgcn_readlane(v, 0);
-    *cv = __builtin_amdgcn_readlane(v, nb);
-    if (F.trace && L->mb_xy == F.trace_mb && lane == 0) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = 4 | satd | (enc == L->recb ? 2 : 0); t[6] = *cu; t[7] = *cv; F.trace[0] = k + 1; } }
+    PCAMV_WAVE_SYNC();
+    int key = 0x7fffffff;
+    if (lane < n) { int cc = L->ccost[lane]; if (cc < PCAMV_COST_MAX) key = (cc << 6) | lane; }
+    key = wave_min_i32(key);
+    EvalRes res;
+    if (key == 0x7fffffff) { res.cost = PCAMV_COST_MAX; res.idx = -1; }
+    else { res.cost = key >> 6; res.idx = key & 63; }
+    if (F.trace && L->mb_xy == F.trace_mb && lane == 0)
+        for (int c = 0; c < n; c++) {
+            if (L->cxy[c] == CAND_NONE) continue;
+            int k = F.trace[0];
+            if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = CAND_X(c); t[4] = CAND_Y(c); t[5] = flags | (enc == L->recb ? 32 : 0); t[6] = L->ccost[c]; t[7] = c; F.trace[0] = k + 1; }
+        }
+    PCAMV_WAVE_SYNC();
+    return res;
 }
-__device__ __forceinline__ int prim_cost_chroma(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int plane, int mx, int my, int satd)
-{
-    int cu, cv;
-    prim_cost_chroma_uv(F, L, enc, ip, xoff, yoff, mx, my, satd, &cu, &cv);
-    return plane ? cv : cu;
-}
+
 /* analyse.c:1535-1567: chroma cost of one 8x8 split below 8x8; mv4[k] = MV of luma 4x4 k (raster in the 8x8) */
 __device__ __forceinline__ int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     int v = 0;
     if (lane < 2) {
@@ -213,14 +248,16 @@ __device__ __forceinline__ int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L
 
 __device__ __forceinline__ void prim_load_fenc(const FrameDev &F, MBLocal *L)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3;
       sts4(L->fenc + row * 16 + c4 * 4, *(const uint32_t *)(F.fenc[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4)); }
     if (lane < 32) {
         int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
         sts4(L->fenc + 256 + row * 16 + plane * 8 + c4 * 4,
-             *(const uint32_t *)(F.fenc[1 + plane] + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4));
+             *(const uint32_t *)((plane ? F.fenc[2] : F.fenc[1]) + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4));
     }
+    PCAMV_WAVE_SYNC();
 }
 
 /* inter prediction of the whole MB from the per-4x4 MVs in L->cmv (x264_mb_mc, common/macroblock.c:483-508,626-690) */
@@ -232,6 +269,7 @@ __device__ __forceinline__ void predict_luma_lane(const FrameDev &F, MBLocal *L,
 }
 __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3, i8 = SCAN8_0 + c4 + 8 * (row >> 2);
       int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
@@ -248,22 +286,26 @@ __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
         }
         sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, o);
     }
+    PCAMV_WAVE_SYNC();
 }
 /* which: 0 luma only, 1 luma+chroma, 2 chroma only; (mvx,mvy) already clipped */
 __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L, int mvx, int mvy, int which)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     if (which != 2) predict_luma_lane(F, L, lane, mvx, mvy);
     if (which != 0 && lane < 32) {
         int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
         sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, chroma_row4(F, plane, L->mb_x * 8 + 4 * c4, L->mb_y * 8 + row, mvx, mvy));
     }
+    PCAMV_WAVE_SYNC();
 }
 
 /* forward 4x4 transform + quantisation + scan score + dequantisation, one 4x4 block per lane:
  * lanes 0..15 luma blocks (x264 block order), 16..19 U, 20..23 V. */
 __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int do_luma, int do_chroma)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     const bool is_l = lane < 16 && do_luma, is_c = lane >= 16 && lane < 24 && do_chroma;
     int16_t d[16];
@@ -286,11 +328,11 @@ __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int
             d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
         }
         if (is_c) { L->red[lane] = d[0]; d[0] = 0; }
-        const int cat = is_l ? 0 : 1, qp = is_l ? F.qp : F.chroma_qp;
+        const int qp = is_l ? F.qp : F.chroma_qp;
         int nz = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            int cls = (i & 1) + ((i >> 2) & 1), mf = F.q_mf[cat][cls], bias = F.q_bias[cat][cls], c = d[i];
+            int cls = (i & 1) + ((i >> 2) & 1), mf = is_l ? F.q_mf[0][cls] : F.q_mf[1][cls], bias = is_l ? F.q_bias[0][cls] : F.q_bias[1][cls], c = d[i];
             c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
             d[i] = (int16_t)c; nz |= c;
         }
@@ -312,15 +354,15 @@ __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int
                 score += decimate_tab4[run];
             }
             const int qbits = qp / 6 - 4;
-            const int *dq = is_l ? F.dq_mf : F.dq_mf_c;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                int cls = (i & 1) + ((i >> 2) & 1);
-                L->coef[lane][i] = qbits >= 0 ? (int16_t)((d[i] * dq[cls]) << qbits) : (int16_t)((d[i] * dq[cls] + (1 << (-qbits - 1))) >> (-qbits));
+                int cls = (i & 1) + ((i >> 2) & 1), dqv = is_l ? F.dq_mf[cls] : F.dq_mf_c[cls];
+                L->coef[lane][i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
             }
         }
         L->blk_nz[lane] = nz; L->blk_score[lane] = score;
     }
+    PCAMV_WAVE_SYNC();
     if (is_c && ((lane - 16) & 3) == 0) {
         /* dct2x2dc over the four raw DCs of this plane */
         int ch = (lane - 16) >> 2;
@@ -328,6 +370,7 @@ __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int
         int d0 = b0 + b1, d1 = b2 + b3, d2 = b0 - b1, d3 = b2 - b3;
         L->cdc[ch][0] = (int16_t)(d0 + d1); L->cdc[ch][1] = (int16_t)(d0 - d1); L->cdc[ch][2] = (int16_t)(d2 + d3); L->cdc[ch][3] = (int16_t)(d2 - d3);
     }
+    PCAMV_WAVE_SYNC();
 }
 
 __device__ __forceinline__ void idct4x4_add(uint8_t *dst, const int16_t *c)   /* dst stride 16 */
@@ -356,6 +399,7 @@ __device__ __forceinline__ void idct4x4_add(uint8_t *dst, const int16_t *c)   /*
 }
 __device__ __forceinline__ void prim_add_idct(const FrameDev &F, MBLocal *L, unsigned keep, int cm0, int cm1)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     if (lane < 16) {
         if (((keep >> lane) & 1) && L->blk_nz[lane]) {
@@ -384,9 +428,11 @@ __device__ __forceinline__ void prim_add_idct(const FrameDev &F, MBLocal *L, uns
         }
     }
     (void)F;
+    PCAMV_WAVE_SYNC();
 }
 __device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     int v = 0;
     if (lane < 16) {
@@ -401,18 +447,21 @@ __device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, in
 }
 __device__ __forceinline__ void prim_copy_pred_to_rec(MBLocal *L)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     ((uint32_t *)L->recb)[lane] = ((const uint32_t *)L->pred)[lane];
     if (lane < 32) ((uint32_t *)L->recb)[64 + lane] = ((const uint32_t *)L->pred)[64 + lane];
+    PCAMV_WAVE_SYNC();
 }
 __device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L)
 {
+    PCAMV_WAVE_SYNC();
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3;
       *(uint32_t *)(F.rec[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4) = lds4(L->pred + row * 16 + c4 * 4); }
     if (lane < 32) {
         int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
-        *(uint32_t *)(F.rec[1 + plane] + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4) = lds4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4);
+        *(uint32_t *)((plane ? F.rec[2] : F.rec[1]) + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4) = lds4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4);
     }
 }
 __device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, int mvx, int mvy)
