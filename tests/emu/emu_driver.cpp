@@ -56,3 +56,5 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
     return 0;
 }
+
+extern "C" void emu_get_stats(long long *out, int reset) { for (int i = 0; i < 32; i++) { out[i] = emu_stats[i]; if (reset) emu_stats[i] = 0; } }

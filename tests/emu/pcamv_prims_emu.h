@@ -9,6 +9,9 @@
 #include <stddef.h>
 #include "pcamv_common.h"
 
+/* work counters for tools/dbg (lists, candidates and lane-passes by kind; macroblock re-encodes) */
+static long long emu_stats[32];
+
 static inline const uint8_t *emu_qpel(const FrameDev &F, uint8_t *tmp, int *st, int px, int py, int mvx, int mvy, int w, int h)
 {
     int qidx = ((mvy & 3) << 2) + (mvx & 3);
@@ -62,6 +65,9 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
 {
     EvalRes r = {PCAMV_COST_MAX, -1};
     const int satd = flags & EV_SATD;
+    { int kind = (flags & EV_FPEL) ? 0 : !satd ? 1 : !(flags & EV_CHROMA) ? 2 : 3, nblk = (pix_w_tab[ip] >> 2) * (pix_h_tab[ip] >> 2);
+      emu_stats[kind]++; emu_stats[4 + kind] += n; emu_stats[8 + kind] += (n * nblk + 63) / 64;
+      if (flags & EV_CHROMA) emu_stats[12] += (n * (nblk / 2) + 63) / 64; if (enc == L->recb) emu_stats[13]++; }
     for (int c = 0; c < n; c++) {
         if (L->cxy[c] == CAND_NONE) { L->ccost[c] = PCAMV_COST_MAX; continue; }
         const int mx = CAND_X(c), my = CAND_Y(c);
@@ -122,6 +128,7 @@ static inline void prim_predict_16x16(const FrameDev &F, MBLocal *L, int mvx, in
 }
 static inline void prim_residual(const FrameDev &F, MBLocal *L, int do_luma, int do_chroma)
 {
+    emu_stats[14]++;
     for (int b = 0; b < 24; b++) {
         int is_l = b < 16;
         if (is_l ? !do_luma : !do_chroma) continue;

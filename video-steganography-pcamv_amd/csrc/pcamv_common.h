@@ -39,6 +39,7 @@ struct FrameDev {
     int w, h, mb_w, mb_h, n_mb;
     int stride, lines, cstride, clines;
     long long plane_size;          /* stride*lines: the four luma planes are contiguous, plane k = luma[0] + k*plane_size */
+    long long cplane_size;         /* the two chroma planes are contiguous too: chroma_base[1] = chroma_base[0] + cplane_size */
     const uint8_t *fenc[3];
     const uint8_t *raw[3];         /* un-padded reference planes the plane-production kernels read */
     uint8_t *luma_base, *chroma_base[2];   /* start of the padded allocations */

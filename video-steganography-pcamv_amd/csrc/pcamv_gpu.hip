@@ -194,7 +194,8 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
         HIPCHK(c, dalloc(&c->d_rec[i], i ? ysz / 4 : ysz));
     }
     HIPCHK(c, dalloc(&c->d_luma, 4 * lsz + 64));
-    HIPCHK(c, dalloc(&c->d_chroma[0], csz + 64)); HIPCHK(c, dalloc(&c->d_chroma[1], csz + 64));
+    HIPCHK(c, dalloc(&c->d_chroma[0], 2 * (csz + 64))); c->d_chroma[1] = c->d_chroma[0] + csz + 64;   /* one allocation: 32-bit offsets reach both */
+    F.cplane_size = (long long)(csz + 64);
     HIPCHK(c, dalloc(&c->d_mb_type, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_ref8, (size_t)F.n_mb * 4)); HIPCHK(c, dalloc(&c->d_prev_ref, (size_t)F.n_mb * 4));
     HIPCHK(c, dalloc(&c->d_mv, (size_t)F.n_mb * 32)); HIPCHK(c, dalloc(&c->d_prev_mv, (size_t)F.n_mb * 32));
     HIPCHK(c, dalloc(&c->d_mv_b, (size_t)F.n_mb * 32)); HIPCHK(c, dalloc(&c->d_ref8_b, (size_t)F.n_mb * 4));
@@ -239,7 +240,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipDeviceSynchronize();
     if (c->self) pcamv_gpu_batch_destroy(c->self);
     for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
-    hipFree(c->d_luma); hipFree(c->d_chroma[0]); hipFree(c->d_chroma[1]);
+    hipFree(c->d_luma); hipFree(c->d_chroma[0]);
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
     hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb); hipFree(c->d_mv_b); hipFree(c->d_ref8_b);
     for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);

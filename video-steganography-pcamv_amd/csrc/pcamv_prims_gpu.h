@@ -109,12 +109,88 @@ __device__ __forceinline__ int wave_min_i32(int v)
                 imin(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+/* global-memory accessors: a wave-uniform base (scalar registers) + a 32-bit per-lane byte offset, so
+ * the loads are `global_load_* v, voffset, s[base]` with no 64-bit vector address arithmetic */
+typedef const __attribute__((address_space(1))) uint8_t *gp8;
+typedef const __attribute__((address_space(1))) int16_t *gp16;
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint64_t __attribute__((aligned(1))) u64u;
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gld4(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u32u *)(base + off); }
+__device__ __forceinline__ uint64_t gld8(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u64u *)(base + off); }
+__device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+
+/* four rows of 4 pixels -> per column x the pair (row0[x], row1[x]) in o[x] and (row2[x], row3[x]) in
+ * o[4 + x], zero-extended to 16 bits: the layout the packed Hadamard works on */
+__device__ __forceinline__ void pk_cols(const uint32_t r[4], uint32_t o[8])
+{
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const uint32_t sel = 0x0c040c00u + (uint32_t)x * 0x00010001u;
+        o[x] = __builtin_amdgcn_perm(r[1], r[0], sel);
+        o[4 + x] = __builtin_amdgcn_perm(r[3], r[2], sel);
+    }
+}
+/* HALF the sum of |4x4 Hadamard of (e - r)| in packed 16-bit arithmetic (two rows per register).
+ * The last butterfly is folded with |a+b| + |a-b| = 2 max(|a|,|b|), so the full sum is even and
+ * x264's satd rounding ((sum_a [+ sum_b]) >> 1, pixel.c:187-253) is exact: it IS this half. */
+__device__ __forceinline__ int satd4x4_half(const uint32_t ec[8], const uint32_t r[4])
+{
+    uint32_t rc[8];
+    pk_cols(r, rc);
+    v2s t[8];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        v2s d0 = as_v2s(ec[4 * g]) - as_v2s(rc[4 * g]), d1 = as_v2s(ec[4 * g + 1]) - as_v2s(rc[4 * g + 1]);
+        v2s d2 = as_v2s(ec[4 * g + 2]) - as_v2s(rc[4 * g + 2]), d3 = as_v2s(ec[4 * g + 3]) - as_v2s(rc[4 * g + 3]);
+        v2s s01 = d0 + d1, d01 = d0 - d1, s23 = d2 + d3, d23 = d2 - d3;
+        t[4 * g] = s01 + s23; t[4 * g + 1] = d01 + d23; t[4 * g + 2] = s01 - s23; t[4 * g + 3] = d01 - d23;
+    }
+    v2s acc = {0, 0};
+    const v2s z = {0, 0};
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        v2s S = t[x] + t[4 + x], D = t[x] - t[4 + x];
+        v2s aS = __builtin_elementwise_max(S, z - S), aD = __builtin_elementwise_max(D, z - D);
+        v2s U = as_v2s(__builtin_amdgcn_perm(as_u32(aD), as_u32(aS), 0x05040100u));   /* (|S.lo|, |D.lo|) */
+        v2s V = as_v2s(__builtin_amdgcn_perm(as_u32(aD), as_u32(aS), 0x07060302u));   /* (|S.hi|, |D.hi|) */
+        acc += __builtin_elementwise_max(U, V);
+    }
+    return (int)acc.x + (int)acc.y;
+}
+
+/* mc_chroma (mc.c:246-277) of a 4x4 block: rows as 8-byte loads, the bilinear weights as one
+ * v_dot4_u32_u8 per output pixel over the bytes {A[i], A[i+1], B[i], B[i+1]} */
+__device__ __forceinline__ void chroma_block4(gp8 cb, uint32_t cstride, uint32_t off, int mvx, int mvy, uint32_t r[4])
+{
+    const int dx = mvx & 7, dy = mvy & 7;
+    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    uint32_t w[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint64_t row = gld8(cb + (size_t)k * cstride, off);
+        const uint32_t lo = (uint32_t)row, hi = (uint32_t)(row >> 32);
+        w[k][0] = lo; w[k][1] = __builtin_amdgcn_alignbit(hi, lo, 8); w[k][2] = __builtin_amdgcn_alignbit(hi, lo, 16); w[k][3] = __builtin_amdgcn_alignbit(hi, lo, 24);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t px = __builtin_amdgcn_perm(w[k + 1][i], w[k][i], 0x05040100u);
+            o |= (__builtin_amdgcn_udot4(px, W, 32u, false) >> 6) << (8 * i);
+        }
+        r[k] = o;
+    }
+}
+
 /* Costs of the n <= 64 candidates listed in L->cxy for the block (ip at xoff,yoff) against the source
  * rows in enc (LDS: L->fenc or L->recb).
- *   luma:   lane = slot * nblk + blk, 64/nblk candidates per pass, passes back to back so that the
- *           loads of all of them are in flight together; each lane fetches its 4x4 reference pixels
- *           (one or two planes, v_lerp_u8), SAD (v_sad_u8) or Hadamard, DPP butterfly over the nblk
- *           lanes, MV bits looked up per lane, the group's first lane stores the total to ccost[c];
+ *   luma:   lane = slot * nblk + blk, 64/nblk candidates per pass, passes back to back; each lane
+ *           fetches its 4x4 reference pixels (one or two planes, v_lerp_u8), SAD (v_sad_u8) or the
+ *           packed Hadamard, DPP butterfly over the nblk lanes, MV bits looked up per lane, the
+ *           group's first lane stores the total to ccost[c];
  *   chroma: (partitions >= 8x8) lane = slot * 2nb + plane * nb + blk, both planes of 128/nblk
  *           candidates per pass, group totals added to ccost[c] with an LDS atomic;
  *   result: lane c reads ccost[c], key = cost << 6 | c, wave minimum -> smallest cost, first index. */
@@ -123,46 +199,52 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
 {
     const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), n = rfl(n_), flags = rfl(flags_), mvp0 = rfl(mvp0_), mvp1 = rfl(mvp1_);
     const int lane = LANE();
-    const int lgn = lg_nblk_tab[ip], lgw = lg_w4_tab[ip], nblk = 1 << lgn;
+    const int lgn = rfl(lg_nblk_tab[ip]), lgw = rfl(lg_w4_tab[ip]), nblk = 1 << lgn;
     const int satd = flags & EV_SATD;
-    const int16_t *cost_tab = F.cost_mv - PCAMV_COST_MV_CENTRE;
+    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     PCAMV_WAVE_SYNC();
     {
         const int slot = lane >> lgn, blk = lane & (nblk - 1);
         const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
-        uint32_t e[4];
+        uint32_t e[4], ec[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) e[k] = lds4(enc + (py + k) * 16 + px);
-        const int gx = L->mb_x * 16 + px, gy = L->mb_y * 16 + py;
+        if (satd) pk_cols(e, ec);
+        const gp8 lb = (gp8)F.luma_base;
+        const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size;
+        const gp8 lb1 = lb + stride, lb2 = lb1 + stride, lb3 = lb2 + stride;
+        const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
         const int cpp = 64 >> lgn;
         for (int p0 = 0; p0 < n; p0 += cpp) {
             const int c = p0 + slot;
             const uint32_t xy = L->cxy[c < n ? c : 0];
             const bool act = c < n && xy != CAND_NONE;
             const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
+            const uint32_t o = rowbase + (uint32_t)((mvy >> 2) * (int)stride + (mvx >> 2));
             uint32_t r[4];
             if (flags & EV_FPEL) {
-                const uint8_t *a = F.luma[0] + (ptrdiff_t)(gy + (mvy >> 2)) * F.stride + gx + (mvx >> 2);
-#pragma unroll
-                for (int k = 0; k < 4; k++) r[k] = ld4u(a + (ptrdiff_t)k * F.stride);
+                r[0] = gld4(lb, o); r[1] = gld4(lb1, o); r[2] = gld4(lb2, o); r[3] = gld4(lb3, o);
             } else {
-                QpelPos q = qpel_pos(F, gx, gy, mvx, mvy);
-#pragma unroll
-                for (int k = 0; k < 4; k++) r[k] = qpel_row(q, F, k);
+                /* get_ref (mc.c:194-243): plane pair by the quarter-pel phase, in arithmetic form of hpel_ref0/1 */
+                const int dx = mvx & 3, dy = mvy & 3;
+                const uint32_t oa = o + (uint32_t)((dx != 0) + 2 * (dy == 2)) * psz + (dy == 3 ? stride : 0u);
+                r[0] = gld4(lb, oa); r[1] = gld4(lb1, oa); r[2] = gld4(lb2, oa); r[3] = gld4(lb3, oa);
+                if ((dx | dy) & 1) {
+                    const uint32_t ob = o + (dy ? (uint32_t)(2 + (dx == 2)) * psz : 0u) + (dx == 3);
+                    r[0] = avg4(r[0], gld4(lb, ob)); r[1] = avg4(r[1], gld4(lb1, ob));
+                    r[2] = avg4(r[2], gld4(lb2, ob)); r[3] = avg4(r[3], gld4(lb3, ob));
+                }
             }
             int v;
-            if (satd) {
-                v = hadamard4x4_abs(e, r);
-                if (lgw >= 1) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }   /* 8x4 units: two 4x4 sums halved together */
-                else v >>= 1;
-            } else {
+            if (satd) v = satd4x4_half(ec, r);
+            else {
                 uint32_t sa = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa);
                 v = (int)sa;
             }
             v = group_sum(v, nblk);
-            if (!(flags & EV_NOMV)) v += (int)cost_tab[(unsigned)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)] + (int)cost_tab[(unsigned)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)];
+            if (!(flags & EV_NOMV)) v += (int)cost_tab[(uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)] + (int)cost_tab[(uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)];
             if (blk == 0 && c < n) L->ccost[c] = act ? v : PCAMV_COST_MAX;
         }
     }
@@ -171,9 +253,13 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
         const int lgnb = lgn - 2, nb = 1 << lgnb, lgcw = lgw - 1;          /* chroma 4x4 blocks per plane: 4,2,2,1 */
         const int slot = lane >> (lgnb + 1), plane = (lane >> lgnb) & 1, blk = lane & (nb - 1);
         const int px = (xoff >> 1) + 4 * (blk & ((1 << lgcw) - 1)), py = (yoff >> 1) + 4 * (blk >> lgcw);
-        uint32_t e[4];
+        uint32_t e[4], ec[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) e[k] = lds4(enc + 256 + (py + k) * 16 + plane * 8 + px);
+        if (satd) pk_cols(e, ec);
+        const gp8 cb = (gp8)F.chroma_base[0];
+        const uint32_t cstride = (uint32_t)F.cstride;
+        const uint32_t rowbase = (uint32_t)plane * (uint32_t)F.cplane_size + (uint32_t)(L->mb_y * 8 + py + PCAMV_CPAD) * cstride + (uint32_t)(L->mb_x * 8 + px + PCAMV_CPAD);
         const int cpp = 64 >> (lgnb + 1);
         for (int p0 = 0; p0 < n; p0 += cpp) {
             const int c = p0 + slot;
@@ -181,14 +267,10 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
             const bool act = c < n && xy != CAND_NONE;
             const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
             uint32_t r[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = chroma_row4(F, plane, L->mb_x * 8 + px, L->mb_y * 8 + py + k, mvx, mvy);
+            chroma_block4(cb, cstride, rowbase + (uint32_t)((mvy >> 3) * (int)cstride + (mvx >> 3)), mvx, mvy, r);
             int v;
-            if (satd) {
-                v = hadamard4x4_abs(e, r);
-                if (lgcw >= 1) { int t = v + dpp_qp1(v); v = (lane & 1) ? 0 : (t >> 1); }
-                else v >>= 1;
-            } else {
+            if (satd) v = satd4x4_half(ec, r);
+            else {
                 uint32_t sa = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa);
