@@ -343,11 +343,29 @@ __device__ __forceinline__ void prim_load_fenc(const FrameDev &F, MBLocal *L)
 }
 
 /* inter prediction of the whole MB from the per-4x4 MVs in L->cmv (x264_mb_mc, common/macroblock.c:483-508,626-690) */
-__device__ __forceinline__ void predict_luma_lane(const FrameDev &F, MBLocal *L, int lane, int mvx, int mvy)
+/* one row of 4 luma pixels at quarter-pel MV (get_ref, mc.c:194-243) */
+__device__ __forceinline__ uint32_t luma_row4(const FrameDev &F, int gx, int gy, int mvx, int mvy)
 {
-    int row = lane >> 2, c4 = lane & 3;
-    QpelPos q = qpel_pos(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
-    sts4(L->pred + row * 16 + 4 * c4, qpel_row(q, F, 0));
+    const gp8 lb = (gp8)F.luma_base;
+    const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size;
+    const uint32_t o = (uint32_t)(gy + PCAMV_PAD + (mvy >> 2)) * stride + (uint32_t)(gx + PCAMV_PAD + (mvx >> 2));
+    const int dx = mvx & 3, dy = mvy & 3;
+    uint32_t r = gld4(lb, o + (uint32_t)((dx != 0) + 2 * (dy == 2)) * psz + (dy == 3 ? stride : 0u));
+    if ((dx | dy) & 1) r = avg4(r, gld4(lb, o + (dy ? (uint32_t)(2 + (dx == 2)) * psz : 0u) + (dx == 3)));
+    return r;
+}
+/* two horizontally adjacent chroma pixels of mc_chroma at chroma position (cx,cy), in bits 0..15 */
+__device__ __forceinline__ uint32_t chroma_px2(const FrameDev &F, int plane, int cx, int cy, int mvx, int mvy)
+{
+    const gp8 cb = (gp8)F.chroma_base[0];
+    const uint32_t cstride = (uint32_t)F.cstride;
+    const uint32_t o = (uint32_t)plane * (uint32_t)F.cplane_size + (uint32_t)(cy + PCAMV_CPAD + (mvy >> 3)) * cstride + (uint32_t)(cx + PCAMV_CPAD + (mvx >> 3));
+    const int dx = mvx & 7, dy = mvy & 7;
+    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    const uint32_t a = gld4(cb, o), b = gld4(cb + cstride, o);
+    const uint32_t p0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b, a, 0x05040100u), W, 32u, false) >> 6;
+    const uint32_t p1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b, a, 0x06050201u), W, 32u, false) >> 6;
+    return p0 | p1 << 8;
 }
 __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
 {
@@ -355,18 +373,13 @@ __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3, i8 = SCAN8_0 + c4 + 8 * (row >> 2);
       int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
-      predict_luma_lane(F, L, lane, mvx, mvy); }
-    if (lane < 32) {
-        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
-        uint32_t o = 0;
-#pragma unroll
-        for (int hlf = 0; hlf < 2; hlf++) {
-            int i8 = SCAN8_0 + (2 * c4 + hlf) + 8 * (row >> 1);
-            int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
-            uint32_t t = chroma_row4(F, plane, L->mb_x * 8 + 4 * c4 + 2 * hlf, L->mb_y * 8 + row, mvx, mvy);
-            o |= (t & 0xFFFFu) << (16 * hlf);
-        }
-        sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, o);
+      sts4(L->pred + row * 16 + 4 * c4, luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy)); }
+    {   /* chroma: every lane two pixels (one 2x2 chroma block row carries one luma 4x4's MV) */
+        int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3;
+        int i8 = SCAN8_0 + c2 + 8 * (row >> 1);
+        int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+        uint32_t t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
+        *(uint16_t *)(L->pred + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
     }
     PCAMV_WAVE_SYNC();
 }
@@ -375,10 +388,11 @@ __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    if (which != 2) predict_luma_lane(F, L, lane, mvx, mvy);
-    if (which != 0 && lane < 32) {
-        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
-        sts4(L->pred + 256 + row * 16 + plane * 8 + 4 * c4, chroma_row4(F, plane, L->mb_x * 8 + 4 * c4, L->mb_y * 8 + row, mvx, mvy));
+    if (which != 2) { int row = lane >> 2, c4 = lane & 3; sts4(L->pred + row * 16 + 4 * c4, luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy)); }
+    if (which != 0) {
+        int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3;
+        uint32_t t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
+        *(uint16_t *)(L->pred + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
     }
     PCAMV_WAVE_SYNC();
 }
@@ -411,37 +425,42 @@ __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int
         }
         if (is_c) { L->red[lane] = d[0]; d[0] = 0; }
         const int qp = is_l ? F.qp : F.chroma_qp;
-        int nz = 0;
+        /* quantise; build the non-zero mask in zigzag order and the "some |level| > 1" flag on the way */
+        unsigned zm = 0; int big = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
+            constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of zz4_tab) */
             int cls = (i & 1) + ((i >> 2) & 1), mf = is_l ? F.q_mf[0][cls] : F.q_mf[1][cls], bias = is_l ? F.q_bias[0][cls] : F.q_bias[1][cls], c = d[i];
             c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
-            d[i] = (int16_t)c; nz |= c;
+            d[i] = (int16_t)c;
+            zm |= (unsigned)(c != 0) << zzinv[i];
+            big |= (unsigned)(c + 1) > 2u;
         }
-        nz = nz != 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) L->coef[lane][i] = d[i];
-        /* decimate score on the zigzag scan (16 coefficients for luma, the 15 AC ones for chroma);
-         * scanned out of LDS: a register array must not be indexed dynamically */
+        const int nz = zm != 0;
+        /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC
+         * ones for chroma): 9 as soon as a level exceeds 1, else the run-length table summed over the
+         * non-zero levels, walked from the top of the mask */
         int score = 0;
         if (nz) {
-            const int16_t *q = L->coef[lane];
-            int idx = 15, lo = is_l ? 0 : 1;
-            while (idx >= lo && q[zz4_tab[idx]] == 0) idx--;
-            while (idx >= lo) {
-                int c = q[zz4_tab[idx--]];
-                if ((unsigned)(c + 1) > 2) { score = 9; break; }
-                int run = 0;
-                while (idx >= lo && q[zz4_tab[idx]] == 0) { idx--; run++; }
-                score += decimate_tab4[run];
+            if (big) score = 9;
+            else {
+                unsigned m = zm; const int lo = is_l ? 0 : 1;
+                while (m) {
+                    int pp = 31 - __builtin_clz(m);
+                    m &= ~(1u << pp);
+                    int pq = m ? 31 - __builtin_clz(m) : lo - 1;
+                    score += (0x56Bu >> (2 * (pp - pq - 1))) & 3u;      /* decimate_tab4[run] */
+                }
             }
             const int qbits = qp / 6 - 4;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 int cls = (i & 1) + ((i >> 2) & 1), dqv = is_l ? F.dq_mf[cls] : F.dq_mf_c[cls];
-                L->coef[lane][i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
+                d[i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
             }
         }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) *(uint32_t *)&L->coef[lane][i] = (uint32_t)(uint16_t)d[i] | (uint32_t)(uint16_t)d[i + 1] << 16;   /* all zero when !nz */
         L->blk_nz[lane] = nz; L->blk_score[lane] = score;
     }
     PCAMV_WAVE_SYNC();
