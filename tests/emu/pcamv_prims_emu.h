@@ -9,6 +9,12 @@
 #include <stddef.h>
 #include "pcamv_common.h"
 
+/* the reference's own tables (common/mc.c:194-200 hpel_ref0/1, dct.h zigzag, quant.c:203 decimate table) for the scalar restatement */
+static const int hpel_ref0_tab[16] = {0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1};
+static const int hpel_ref1_tab[16] = {0, 0, 0, 0, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 3, 2};
+static const unsigned char zz4_tab[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
+static const unsigned char decimate_tab4[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 /* work counters for tools/dbg (lists, candidates and lane-passes by kind; macroblock re-encodes) */
 static long long emu_stats[32];
 
@@ -49,7 +55,7 @@ static inline int emu_cmp(int w, int h, const uint8_t *a, int sa, const uint8_t 
 }
 static inline int prim_cost_luma_nolog(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int mx, int my, int satd)
 {
-    uint8_t tmp[32 * 20]; int st, w = pix_w_tab[ip], h = pix_h_tab[ip];
+    uint8_t tmp[32 * 20]; int st, w = pix_w_of(ip), h = pix_h_of(ip);
     const uint8_t *r = emu_qpel(F, tmp, &st, L->mb_x * 16 + xoff, L->mb_y * 16 + yoff, mx, my, w, h);
     return emu_cmp(w, h, enc + yoff * 16 + xoff, 16, r, st, satd);
 }
@@ -65,7 +71,7 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
 {
     EvalRes r = {PCAMV_COST_MAX, -1};
     const int satd = flags & EV_SATD;
-    { int kind = (flags & EV_FPEL) ? 0 : !satd ? 1 : !(flags & EV_CHROMA) ? 2 : 3, nblk = (pix_w_tab[ip] >> 2) * (pix_h_tab[ip] >> 2);
+    { int kind = (flags & EV_FPEL) ? 0 : !satd ? 1 : !(flags & EV_CHROMA) ? 2 : 3, nblk = (pix_w_of(ip) >> 2) * (pix_h_of(ip) >> 2);
       emu_stats[kind]++; emu_stats[4 + kind] += n; emu_stats[8 + kind] += (n * nblk + 63) / 64;
       if (flags & EV_CHROMA) emu_stats[12] += (n * (nblk / 2) + 63) / 64; if (enc == L->recb) emu_stats[13]++; }
     for (int c = 0; c < n; c++) {
@@ -74,7 +80,7 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
         int cost = prim_cost_luma_nolog(F, L, enc, ip, xoff, yoff, mx, my, satd);
         if (!(flags & EV_NOMV)) cost += F.cost_mv[mx - mvp0] + F.cost_mv[my - mvp1];
         if (flags & EV_CHROMA) {
-            uint8_t tmp[8 * 8]; int w = pix_w_tab[ip] / 2, h = pix_h_tab[ip] / 2;
+            uint8_t tmp[8 * 8]; int w = pix_w_of(ip) / 2, h = pix_h_of(ip) / 2;
             for (int p = 0; p < 2; p++) {
                 emu_mc_chroma(F, tmp, 8, p, L->mb_x * 8 + (xoff >> 1), L->mb_y * 8 + (yoff >> 1), mx, my, w, h);
                 int cc = emu_cmp(w, h, enc + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
@@ -133,7 +139,7 @@ static inline void prim_residual(const FrameDev &F, MBLocal *L, int do_luma, int
         int is_l = b < 16;
         if (is_l ? !do_luma : !do_chroma) continue;
         int ch = (b - 16) >> 2, ci = (b - 16) & 3;
-        int px = is_l ? 4 * blk_x_tab[b] : ch * 8 + (ci & 1) * 4, py = is_l ? 4 * blk_y_tab[b] : 16 + (ci >> 1) * 4;
+        int px = is_l ? 4 * blk_x_of(b) : ch * 8 + (ci & 1) * 4, py = is_l ? 4 * blk_y_of(b) : 16 + (ci >> 1) * 4;
         int16_t d[4][4], t[4][4], c[16];
         for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y][x] = L->fenc[(py + y) * 16 + px + x] - L->pred[(py + y) * 16 + px + x];
         for (int i = 0; i < 4; i++) {
@@ -195,7 +201,7 @@ static inline void emu_idct_add(uint8_t *dst, const int16_t *c)
 static inline void prim_add_idct(const FrameDev &F, MBLocal *L, unsigned keep, int cm0, int cm1)
 {
     (void)F;
-    for (int b = 0; b < 16; b++) if (((keep >> b) & 1) && L->blk_nz[b]) emu_idct_add(L->pred + 4 * blk_y_tab[b] * 16 + 4 * blk_x_tab[b], L->coef[b]);
+    for (int b = 0; b < 16; b++) if (((keep >> b) & 1) && L->blk_nz[b]) emu_idct_add(L->pred + 4 * blk_y_of(b) * 16 + 4 * blk_x_of(b), L->coef[b]);
     for (int b = 16; b < 24; b++) {
         int ch = (b - 16) >> 2, ci = (b - 16) & 3, mode = ch ? cm1 : cm0;
         uint8_t *dst = L->pred + 256 + (ci >> 1) * 4 * 16 + ch * 8 + (ci & 1) * 4;

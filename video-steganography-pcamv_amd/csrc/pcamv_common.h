@@ -68,17 +68,19 @@ struct FrameDev {
     int *trace; int trace_mb;      /* diagnostics: log every block-cost evaluation of one MB (trace[0] = count) */
 };
 
-PCAMV_CONST int pix_w_tab[7] = {16, 16, 8, 8, 8, 4, 4};
-PCAMV_CONST int pix_h_tab[7] = {16, 8, 16, 8, 4, 8, 4};
-PCAMV_CONST unsigned char blk_x_tab[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3};
-PCAMV_CONST unsigned char blk_y_tab[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
-PCAMV_CONST int hpel_ref0_tab[16] = {0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1};
-PCAMV_CONST int hpel_ref1_tab[16] = {0, 0, 0, 0, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 3, 2};
-/* zigzag (frame) scan position k -> raster index of the 4x4 coefficient array as dct.c stores it */
-PCAMV_CONST unsigned char zz4_tab[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
-PCAMV_CONST unsigned char decimate_tab4[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-PCAMV_DEV int scan8_of(int idx) { return SCAN8_0 + blk_x_tab[idx] + 8 * blk_y_tab[idx]; }
+/* Small lookup tables live in registers as packed constants: a table in memory costs one global
+ * load round trip per use, and these sit on the serial chain of the search (me.c tables, block
+ * geometry of common/macroblock.c).  4 bits per entry, biased where entries are signed. */
+PCAMV_DEV int nib32(unsigned k, int i) { return (int)((k >> (4 * i)) & 15u); }
+PCAMV_DEV int nib64(unsigned long long k, int i) { return (int)((k >> (4 * i)) & 15ull); }
+PCAMV_DEV int lg_w4_of(int ip) { return nib32(0x0011122u, ip); }          /* log2(width / 4):  16,16,8,8,8,4,4 */
+PCAMV_DEV int lg_h4_of(int ip) { return nib32(0x0101212u, ip); }          /* log2(height / 4): 16,8,16,8,4,8,4 */
+PCAMV_DEV int lg_nblk_of(int ip) { return nib32(0x0112334u, ip); }        /* log2 of 4x4 blocks per partition */
+PCAMV_DEV int pix_w_of(int ip) { return 4 << lg_w4_of(ip); }
+PCAMV_DEV int pix_h_of(int ip) { return 4 << lg_h4_of(ip); }
+PCAMV_DEV int blk_x_of(int idx) { return (idx & 1) | ((idx >> 1) & 2); }  /* x264 block order -> 4x4 column / row */
+PCAMV_DEV int blk_y_of(int idx) { return ((idx >> 1) & 1) | ((idx >> 2) & 2); }
+PCAMV_DEV int scan8_of(int idx) { return SCAN8_0 + blk_x_of(idx) + 8 * blk_y_of(idx); }
 PCAMV_DEV int clip3i(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 PCAMV_DEV int iabs(int v) { return v < 0 ? -v : v; }
 PCAMV_DEV int imin(int a, int b) { return a < b ? a : b; }

@@ -159,14 +159,21 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
 }
 
 /* ---------------------------------------------------------------- motion search */
-PCAMV_CONST int subpel_iter_tab[10][4] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {0, 2, 1, 1},
-                                          {0, 2, 1, 2}, {0, 0, 2, 2}, {0, 0, 2, 2}, {0, 0, 4, 10}, {0, 0, 4, 10}};
-PCAMV_CONST int mod6m1_tab[8] = {5, 0, 1, 2, 3, 4, 5, 0};
-PCAMV_CONST int hex2_tab[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
-PCAMV_CONST int hex4_tab[16][2] = {{-4, 2}, {-4, 1}, {-4, 0}, {-4, -1}, {-4, -2}, {4, -2}, {4, -1}, {4, 0},
-                                   {4, 1},  {4, 2},  {2, 3},  {0, 4},   {-2, 3},  {-2, -3}, {0, -4}, {2, -3}};
-PCAMV_CONST int range_mul_tab[4][4] = {{3, 3, 4, 4}, {3, 4, 4, 4}, {4, 4, 4, 5}, {4, 4, 5, 6}};
-PCAMV_CONST int size_shift_tab[7] = {0, 1, 1, 2, 3, 3, 4};
+/* me.c / analyse.c tables as packed constants (see pcamv_common.h) */
+/* subpel_iterations[subme] = {hpel0, qpel0, hpel1, qpel1}: {0,0,0,0},{1,1,0,0},{0,1,1,0},{0,2,1,0},{0,2,1,1},{0,2,1,2},{0,0,2,2},{0,0,2,2},{0,0,4,10},{0,0,4,10} */
+PCAMV_DEV int subpel_iter_of(int subme, int k)
+{
+    if (subme < 4) return nib64(0x0120011000110000ull, 4 * subme + k);
+    if (subme < 8) return nib64(0x2200220021201120ull, 4 * (subme - 4) + k);
+    return nib32(0xa400a400u, 4 * (subme - 8) + k);
+}
+PCAMV_DEV int mod6m1_of(int i) { return nib32(0x05432105u, i); }                                   /* {5,0,1,2,3,4,5,0} */
+PCAMV_DEV int hex2_x(int i) { return nib32(0x01343101u, i) - 2; }                                  /* {-1,-2,-1,1,2,1,-1,-2} */
+PCAMV_DEV int hex2_y(int i) { return nib32(0x20024420u, i) - 2; }                                  /* {-2,0,2,2,0,-2,-2,0} */
+PCAMV_DEV int hex4_x(int j) { return nib64(0x6422468888800000ull, j) - 4; }                        /* {-4,-4,-4,-4,-4,4,4,4,4,4,2,0,-2,-2,0,2} */
+PCAMV_DEV int hex4_y(int j) { return nib64(0x1017876543223456ull, j) - 4; }                        /* {2,1,0,-1,-2,-2,-1,0,1,2,3,4,3,-3,-4,-3} */
+PCAMV_DEV int range_mul_of(int mvd_ctx, int sad_ctx) { return nib64(0x6544544444434433ull, 4 * mvd_ctx + sad_ctx); } /* {3,3,4,4},{3,4,4,4},{4,4,4,5},{4,4,5,6} */
+PCAMV_DEV int size_shift_of(int ip) { return nib32(0x4332110u, ip); }                              /* {0,1,1,2,3,3,4} */
 
 #define MVCOSTX(v) ((int)F.cost_mv[(v) - me->mvp[0]])
 #define MVCOSTY(v) ((int)F.cost_mv[(v) - me->mvp[1]])
@@ -268,21 +275,21 @@ PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, 
                           int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
 {
     int dir = -2;
-    FOR_CAND(c, 6) L->cxy[c] = CAND_PACK((bmx + hex2_tab[c + 1][0]) * 4, (bmy + hex2_tab[c + 1][1]) * 4);
+    FOR_CAND(c, 6) L->cxy[c] = CAND_PACK((bmx + hex2_x(c + 1)) * 4, (bmy + hex2_y(c + 1)) * 4);
     {
         EvalRes r = eval_cands(F, L, me, L->fenc, 6, EV_FPEL);
         if (r.cost < bcost) { bcost = r.cost; dir = r.idx; }
     }
     if (dir != -2) {
-        bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
+        bmx += hex2_x(dir + 1); bmy += hex2_y(dir + 1);
         for (int i = 1; i < i_me_range / 2 && CHECK_MVRANGE(bmx, bmy); i++) {
-            const int odir = mod6m1_tab[dir + 1];
-            FOR_CAND(c, 3) L->cxy[c] = CAND_PACK((bmx + hex2_tab[odir + c][0]) * 4, (bmy + hex2_tab[odir + c][1]) * 4);
+            const int odir = mod6m1_of(dir + 1);
+            FOR_CAND(c, 3) L->cxy[c] = CAND_PACK((bmx + hex2_x(odir + c)) * 4, (bmy + hex2_y(odir + c)) * 4);
             EvalRes r = eval_cands(F, L, me, L->fenc, 3, EV_FPEL);
             dir = -2;
             if (r.cost < bcost) { bcost = r.cost; dir = odir - 1 + r.idx; }
             if (dir == -2) break;
-            bmx += hex2_tab[dir + 1][0]; bmy += hex2_tab[dir + 1][1];
+            bmx += hex2_x(dir + 1); bmy += hex2_y(dir + 1);
         }
     }
     int omx = bmx, omy = bmy;
@@ -343,7 +350,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
         hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
-#define SAD_THRESH(v) (bcost < ((v) >> size_shift_tab[ip]))
+#define SAD_THRESH(v) (bcost < ((v) >> size_shift_of(ip)))
         ucost1 = bcost;
         if (pmx | pmy) { TRY8(0, 0, pmx, pmy - 1, pmx, pmy + 1, pmx - 1, pmy, pmx + 1, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
         else { TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
@@ -376,7 +383,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                     }
                     sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
                     mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
-                    i_me_range = i_me_range * range_mul_tab[mvd_ctx][sad_ctx] / 4;
+                    i_me_range = i_me_range * range_mul_of(mvd_ctx, sad_ctx) / 4;
                 }
                 cross_search(F, L, me, bmx, bmy, bcost, omx, omy, cross_start, i_me_range, i_me_range / 2, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
                 TRY4(omx, omy, -2, -2, -2, 2, 2, -2, 2, 2);
@@ -387,7 +394,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                     const int n = imin(64, total - base);
                     FOR_CAND(c, n) {
                         int g = base + c, i = 1 + (g >> 4), j = g & 15;
-                        int mx = omx + hex4_tab[j][0] * i, my = omy + hex4_tab[j][1] * i;
+                        int mx = omx + hex4_x(j) * i, my = omy + hex4_y(j) * i;
                         L->cxy[c] = CHECK_MVRANGE(mx, my) ? CAND_PACK(mx * 4, my * 4) : CAND_NONE;
                     }
                     fpel_fold(F, L, me, bmx, bmy, bcost, n);
@@ -403,13 +410,13 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     else { me->mv[0] = bmx * 4; me->mv[1] = bmy * 4; me->cost = bcost; }
     me->cost_mv = MVCOSTX(me->mv[0]) + MVCOSTY(me->mv[1]);
     if (bmx == pmx && bmy == pmy && F.subme < 3) me->cost += me->cost_mv;
-    if (F.subme >= 2) refine_subpel(F, L, me, subpel_iter_tab[F.subme][2], subpel_iter_tab[F.subme][3], 0);
+    if (F.subme >= 2) refine_subpel(F, L, me, subpel_iter_of(F.subme, 2), subpel_iter_of(F.subme, 3), 0);
     else if (me->mv[1] > L->mv_max_spel[1]) me->mv[1] = L->mv_max_spel[1];
 }
 
 PCAMV_DEV void me_refine_qpel(const FrameDev &F, MBLocal *L, MEState *me)
 {
-    refine_subpel(F, L, me, subpel_iter_tab[F.subme][0], subpel_iter_tab[F.subme][1], 1);
+    refine_subpel(F, L, me, subpel_iter_of(F.subme, 0), subpel_iter_of(F.subme, 1), 1);
 }
 
 /* ---------------------------------------------------------------- macroblock (re-)encode */
@@ -621,13 +628,13 @@ PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8
     for (int k = 0; k < n; k++) {
         int idx = 4 * i8 + (pixel == PIX_8x4 ? 2 * k : k);
         MEState *me = pixel == PIX_4x4 ? &a->me4x4[i8][k] : pixel == PIX_8x4 ? &a->me8x4[i8][k] : &a->me4x8[i8][k];
-        me_setup(me, pixel, 4 * blk_x_tab[idx], 4 * blk_y_tab[idx]);
+        me_setup(me, pixel, 4 * blk_x_of(idx), 4 * blk_y_of(idx));
         predict_mv(L, idx, pixel == PIX_8x4 ? 2 : 1, me->mvp);
         int mvc[1][2];
         const MEState *cand = pixel == PIX_4x4 ? &a->me8x8[i8] : &a->me4x4[i8][0];
         mvc[0][0] = cand->mv[0]; mvc[0][1] = cand->mv[1];
         me_search(F, L, me, mvc, k == 0);
-        cache_mv_set(L, blk_x_tab[idx], blk_y_tab[idx], pixel == PIX_8x4 ? 2 : 1, pixel == PIX_4x8 ? 2 : 1, me->mv[0], me->mv[1]);
+        cache_mv_set(L, blk_x_of(idx), blk_y_of(idx), pixel == PIX_8x4 ? 2 : 1, pixel == PIX_4x8 ? 2 : 1, me->mv[0], me->mv[1]);
         cost += me->cost;
     }
     cost += F.lambda * (pixel == PIX_4x4 ? 5 : 3);
@@ -643,8 +650,11 @@ PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8
     if (pixel == PIX_4x4) a->cost4x4[i8] = cost; else if (pixel == PIX_8x4) a->cost8x4[i8] = cost; else a->cost4x8[i8] = cost;
 }
 
-PCAMV_CONST signed char d_mv_tab[12][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-2, 1}, {-1, 2}, {1, 2}, {2, 1}, {2, -1}, {1, -2}, {-1, -2}, {-2, -1}};
-PCAMV_CONST signed char d_nb_tab[9][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {0, 0}};
+/* d_mv: {0,-1},{1,0},{0,1},{-1,0},{-2,1},{-1,2},{1,2},{2,1},{2,-1},{1,-2},{-1,-2},{-2,-1}   d_nb: {0,-1},{1,0},{0,1},{-1,0},{-1,-1},{-1,1},{1,-1},{1,1},{0,0} */
+PCAMV_DEV int d_mv_x(int i) { return nib64(0x013443101232ull, i) - 2; }
+PCAMV_DEV int d_mv_y(int i) { return nib64(0x100134432321ull, i) - 2; }
+PCAMV_DEV int d_nb_x(int i) { return nib64(0x122000121ull, i) - 1; }
+PCAMV_DEV int d_nb_y(int i) { return nib64(0x120201210ull, i) - 1; }
 
 /* nine neighbourhood costs around (cx,cy) on the current reconstruction (MV_SATD_FDEC_IH: metric of
  * the reconstructed block against the reference at the candidate MV + MV bits + chroma for
@@ -652,7 +662,7 @@ PCAMV_CONST signed char d_nb_tab[9][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1,
 PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, int cx, int cy, int nb_cost, int *last)
 {
     const int flags = (F.subme > 1 ? EV_SATD : 0) | ((F.b_chroma_me && me->i_pixel <= PIX_8x8) ? EV_CHROMA : 0);
-    FOR_CAND(c, 9) L->cxy[c] = CAND_PACK(cx + d_nb_tab[c][0], cy + d_nb_tab[c][1]);
+    FOR_CAND(c, 9) L->cxy[c] = CAND_PACK(cx + d_nb_x(c), cy + d_nb_y(c));
     EvalRes r = eval_cands(F, L, me, L->recb, 9, flags);
     if (nb_cost) { FOR_CAND(c, 9) L->nbc[c] = L->ccost[c]; PCAMV_WAVE_SYNC(); }
     *last = L->ccost[8];
@@ -672,18 +682,18 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
     min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
     int ii_best = -1;
     for (int ii = 0; ii < 12; ii++) {
-        int bx1 = bmx + d_mv_tab[ii][0], by1 = bmy + d_mv_tab[ii][1];
+        int bx1 = bmx + d_mv_x(ii), by1 = bmy + d_mv_y(ii);
         me->mv[0] = bx1; me->mv[1] = by1;
         update_cache(L, a); mb_encode(F, L); prim_copy_pred_to_rec(L);
         int min1 = rca_nine(F, L, me, bx1, by1, 0, &cost);
         int is_opt = (min1 == cost);
-        if (is_opt == want_optimal && cost < min_cost) { min_cost = cost; *m_x = d_mv_tab[ii][0]; *m_y = d_mv_tab[ii][1]; ii_best = ii; }
+        if (is_opt == want_optimal && cost < min_cost) { min_cost = cost; *m_x = d_mv_x(ii); *m_y = d_mv_y(ii); ii_best = ii; }
         if (ii == 3 && min_cost != PCAMV_COST_MAX) break;
     }
     if (min_cost == PCAMV_COST_MAX) {
         b_error_pos = 1; b_1_neighbor = 1;
         *m_x = 0; *m_y = 0;
-        for (int k = 0; k < 4; k++) if (L->nbc[k] < min_cost) { min_cost = L->nbc[k]; *m_x = d_nb_tab[k][0]; *m_y = d_nb_tab[k][1]; }
+        for (int k = 0; k < 4; k++) if (L->nbc[k] < min_cost) { min_cost = L->nbc[k]; *m_x = d_nb_x(k); *m_y = d_nb_y(k); }
     } else b_1_neighbor = ii_best <= 3;
     int cost_opt = min_cost > me->cost_rec ? min_cost - me->cost_rec : 1;
     if (!b_1_neighbor) cost_opt = (int)(beta1 * (float)cost_opt);
@@ -797,7 +807,7 @@ PCAMV_DEV void slot_geometry(int i_type, int i_partition, const uint8_t *sub, in
 {
     if (i_type == PCAMV_P_8x8) {
         int i = slot >> 2;
-        *xoff = 4 * blk_x_tab[slot]; *yoff = 4 * blk_y_tab[slot];
+        *xoff = 4 * blk_x_of(slot); *yoff = 4 * blk_y_of(slot);
         *ip = sub[i] == PCAMV_D_L0_8x8 ? PIX_8x8 : sub[i] == PCAMV_D_L0_4x8 ? PIX_4x8 : sub[i] == PCAMV_D_L0_8x4 ? PIX_8x4 : PIX_4x4;
     } else if (i_partition == PCAMV_D_16x16) { *ip = PIX_16x16; *xoff = 0; *yoff = 0; }
     else if (i_partition == PCAMV_D_8x16) { *ip = PIX_8x16; *xoff = slot ? 8 : 0; *yoff = 0; }

@@ -43,26 +43,6 @@ __device__ __forceinline__ int wave_sum_all(int v)
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-/* one row (4 pixels) of the quarter-pel reference sample, get_ref semantics */
-struct QpelPos { const uint8_t *a, *b; int two; };
-__device__ __forceinline__ QpelPos qpel_pos(const FrameDev &F, int px, int py, int mvx, int mvy)
-{
-    QpelPos q;
-    int qidx = ((mvy & 3) << 2) + (mvx & 3);
-    ptrdiff_t off = (ptrdiff_t)(py + (mvy >> 2)) * F.stride + px + (mvx >> 2);
-    /* plane chosen by pointer arithmetic: the index is lane-varying, F lives in scalar registers */
-    q.a = F.luma[0] + (ptrdiff_t)hpel_ref0_tab[qidx] * F.plane_size + off + ((mvy & 3) == 3) * F.stride;
-    q.two = (qidx & 5) != 0;
-    q.b = F.luma[0] + (ptrdiff_t)hpel_ref1_tab[qidx] * F.plane_size + off + ((mvx & 3) == 3);
-    return q;
-}
-__device__ __forceinline__ uint32_t qpel_row(const QpelPos &q, const FrameDev &F, int r)
-{
-    uint32_t a = ld4u(q.a + (ptrdiff_t)r * F.stride);
-    if (q.two) a = avg4(a, ld4u(q.b + (ptrdiff_t)r * F.stride));
-    return a;
-}
-
 __device__ __forceinline__ int hadamard4x4_abs(const uint32_t e[4], const uint32_t r[4])
 {
     int t[4][4], s = 0;
@@ -98,8 +78,6 @@ __device__ __forceinline__ uint32_t chroma_row4(const FrameDev &F, int plane, in
     return o;
 }
 
-PCAMV_CONST unsigned char lg_nblk_tab[7] = {4, 3, 3, 2, 1, 1, 0};   /* log2 of the 4x4 blocks per partition */
-PCAMV_CONST unsigned char lg_w4_tab[7] = {2, 2, 1, 1, 1, 0, 0};     /* log2 of the partition width in 4x4 blocks */
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int wave_min_i32(int v)
@@ -199,7 +177,7 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
 {
     const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), n = rfl(n_), flags = rfl(flags_), mvp0 = rfl(mvp0_), mvp1 = rfl(mvp1_);
     const int lane = LANE();
-    const int lgn = rfl(lg_nblk_tab[ip]), lgw = rfl(lg_w4_tab[ip]), nblk = 1 << lgn;
+    const int lgn = lg_nblk_of(ip), lgw = lg_w4_of(ip), nblk = 1 << lgn;
     const int satd = flags & EV_SATD;
     const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     PCAMV_WAVE_SYNC();
@@ -407,8 +385,8 @@ __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int
     int16_t d[16];
     if (is_l || is_c) {
         int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
-        int px = is_l ? 4 * blk_x_tab[lane] : ch * 8 + (ci & 1) * 4;
-        int py = is_l ? 4 * blk_y_tab[lane] : 16 + (ci >> 1) * 4;
+        int px = is_l ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4;
+        int py = is_l ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
         int t[4][4];
 #pragma unroll
         for (int y = 0; y < 4; y++) {
@@ -507,7 +485,7 @@ __device__ __forceinline__ void prim_add_idct(const FrameDev &F, MBLocal *L, uns
             int16_t c[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) c[i] = L->coef[lane][i];
-            idct4x4_add(L->pred + 4 * blk_y_tab[lane] * 16 + 4 * blk_x_tab[lane], c);
+            idct4x4_add(L->pred + 4 * blk_y_of(lane) * 16 + 4 * blk_x_of(lane), c);
         }
     } else if (lane < 24) {
         int ch = (lane - 16) >> 2, ci = (lane - 16) & 3, mode = ch ? cm1 : cm0;
