@@ -73,7 +73,7 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
     const int satd = flags & EV_SATD;
     { int kind = (flags & EV_FPEL) ? 0 : !satd ? 1 : !(flags & EV_CHROMA) ? 2 : 3, nblk = (pix_w_of(ip) >> 2) * (pix_h_of(ip) >> 2);
       emu_stats[kind]++; emu_stats[4 + kind] += n; emu_stats[8 + kind] += (n * nblk + 63) / 64;
-      if (flags & EV_CHROMA) emu_stats[12] += (n * (nblk / 2) + 63) / 64; if (enc == L->recb) emu_stats[13]++; }
+      if (flags & EV_CHROMA) emu_stats[12] += (n * (nblk / 2) + 63) / 64; if (enc == L->recb || enc == L->recb0) emu_stats[13]++; }
     for (int c = 0; c < n; c++) {
         if (L->cxy[c] == CAND_NONE) { L->ccost[c] = PCAMV_COST_MAX; continue; }
         const int mx = CAND_X(c), my = CAND_Y(c);
@@ -89,7 +89,7 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
         }
         L->ccost[c] = cost;
         if (cost < r.cost) { r.cost = cost; r.idx = c; }
-        if (F.trace && L->mb_xy == F.trace_mb) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = flags | (enc == L->recb ? 32 : 0); t[6] = cost; t[7] = c; F.trace[0] = k + 1; } }
+        if (F.trace && L->mb_xy == F.trace_mb) { int k = F.trace[0]; if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = mx; t[4] = my; t[5] = flags | ((enc == L->recb || enc == L->recb0) ? 32 : 0); t[6] = cost; t[7] = c; F.trace[0] = k + 1; } }
     }
     return r;
 }
@@ -215,7 +215,7 @@ static inline int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
     for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { int d = L->fenc[256 + y * 16 + ch * 8 + x] - L->pred[256 + y * 16 + ch * 8 + x]; s += d * d; }
     return s;
 }
-static inline void prim_copy_pred_to_rec(MBLocal *L) { memcpy(L->recb, L->pred, sizeof(L->recb)); }
+static inline void prim_copy_pred(MBLocal *L, uint8_t *dst) { memcpy(dst, L->pred, sizeof(L->recb)); }
 static inline void prim_store_rec(const FrameDev &F, MBLocal *L)
 {
     for (int y = 0; y < 16; y++) memcpy(F.rec[0] + (size_t)(L->mb_y * 16 + y) * F.w + L->mb_x * 16, L->pred + y * 16, 16);

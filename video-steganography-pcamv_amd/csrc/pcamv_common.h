@@ -92,6 +92,7 @@ PCAMV_DEV int median3i(int a, int b, int c) { return imax(imin(a, b), imin(imax(
 struct MBLocal {
     uint8_t fenc[24 * 16];         /* Y 16x16 then U|V 8x8 side by side, stride 16 (x264 fenc_buf layout) */
     uint8_t recb[24 * 16];         /* reconstruction in the same layout (fenc_buf_ih) */
+    uint8_t recb0[24 * 16];        /* reconstruction of the macroblock as decided: shared by all its carriers' first RCA step */
     uint8_t pred[24 * 16];         /* prediction -> reconstruction, same layout */
     int16_t coef[24][16];          /* per 4x4 block coefficients (luma 0..15, U 16..19, V 20..23) */
     int16_t cdc[2][4];

@@ -87,7 +87,7 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
     MEState *me = slot_me(L, a, slots[k]);
     int dx = 0, dy = 0;
     const int bx = me->mv[0], by = me->mv[1];
-    const int cost = rca_mv_cost(F, L, a, me, &dx, &dy);
+    const int cost = rca_mv_cost(F, L, a, me, &dx, &dy, 0);
     if (PCAMV_LANE0) {
         pcamv_mb_t *r = &F.rec_mb[xy];
         r->mv_stego[slots[k]][0] = (int16_t)(bx + dx); r->mv_stego[slots[k]][1] = (int16_t)(by + dy);
@@ -95,28 +95,31 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
     }
 }
 
-/* phases B + C of one macroblock back to back (dataflow schedule): every carrier's replacement-MV
- * cost, then the pass-1 reconstruction.  rca_mv_cost leaves the decided MVs and the cache as it found
- * them, so one rebuild of the analysis serves all carriers and the final encode. */
+/* phases C + B of one macroblock back to back (dataflow schedule): the pass-1 reconstruction, then
+ * every carrier's replacement-MV cost.  The reconstruction of the macroblock as decided is also the
+ * first re-encode of every carrier's RCA step, so it is made once (L->recb0); rca_mv_cost leaves the
+ * decided MVs and the cache as it found them, so one rebuild of the analysis serves all carriers. */
 PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
 {
     int *slots = L->slots;
     const int n = analysis_from_record(F, L, a, xy, slots);
-    if (F.rec_mb[xy].used)
+    update_cache(L, a);
+    mb_encode(F, L);
+    prim_store_rec(F, L);
+    if (F.rec_mb[xy].used && n > 0) {
+        prim_copy_pred(L, L->recb0);
         for (int k = 0; k < n; k++) {
             MEState *me = slot_me(L, a, slots[k]);
             int dx = 0, dy = 0;
             const int bx = me->mv[0], by = me->mv[1];
-            const int cost = rca_mv_cost(F, L, a, me, &dx, &dy);
+            const int cost = rca_mv_cost(F, L, a, me, &dx, &dy, 1);
             if (PCAMV_LANE0) {
                 pcamv_mb_t *r = &F.rec_mb[xy];
                 r->mv_stego[slots[k]][0] = (int16_t)(bx + dx); r->mv_stego[slots[k]][1] = (int16_t)(by + dy);
                 r->inter_stego_cost[slots[k]] = cost;
             }
         }
-    update_cache(L, a);
-    mb_encode(F, L);
-    prim_store_rec(F, L);
+    }
 }
 
 PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)

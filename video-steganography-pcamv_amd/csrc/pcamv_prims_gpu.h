@@ -272,7 +272,7 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
         for (int c = 0; c < n; c++) {
             if (L->cxy[c] == CAND_NONE) continue;
             int k = F.trace[0];
-            if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = CAND_X(c); t[4] = CAND_Y(c); t[5] = flags | (enc == L->recb ? 32 : 0); t[6] = L->ccost[c]; t[7] = c; F.trace[0] = k + 1; }
+            if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = CAND_X(c); t[4] = CAND_Y(c); t[5] = flags | ((enc == L->recb || enc == L->recb0) ? 32 : 0); t[6] = L->ccost[c]; t[7] = c; F.trace[0] = k + 1; }
         }
     PCAMV_WAVE_SYNC();
     return res;
@@ -524,12 +524,12 @@ __device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, in
     (void)F;
     return __builtin_amdgcn_readlane(v, 0);
 }
-__device__ __forceinline__ void prim_copy_pred_to_rec(MBLocal *L)
+__device__ __forceinline__ void prim_copy_pred(MBLocal *L, uint8_t *dst)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    ((uint32_t *)L->recb)[lane] = ((const uint32_t *)L->pred)[lane];
-    if (lane < 32) ((uint32_t *)L->recb)[64 + lane] = ((const uint32_t *)L->pred)[64 + lane];
+    ((uint32_t *)dst)[lane] = ((const uint32_t *)L->pred)[lane];
+    if (lane < 32) ((uint32_t *)dst)[64 + lane] = ((const uint32_t *)L->pred)[64 + lane];
     PCAMV_WAVE_SYNC();
 }
 __device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L)
