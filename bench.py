@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gops", type=int, default=128, help="closed GOPs in flight per GPU (batched into every launch)")
+    ap.add_argument("--gops", type=int, default=256, help="closed GOPs in flight per GPU (batched into every launch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088, help="coded height (1080 rounded up to 16)")
     ap.add_argument("--me", default="umh")

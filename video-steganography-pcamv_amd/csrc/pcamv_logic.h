@@ -20,18 +20,22 @@
 #include "pcamv_common.h"
 
 /* ---------------------------------------------------------------- neighbour context */
+/* x264_macroblock_cache_mv / _ref (common/macroblock.h): fill a w x h patch of 4x4 positions; one
+ * position per lane */
 PCAMV_DEV void cache_mv_set(MBLocal *L, int x, int y, int w, int h, int mvx, int mvy)
 {
-    for (int j = 0; j < h; j++)
-        for (int i = 0; i < w; i++) {
-            L->cmv[SCAN8_0 + x + i + 8 * (y + j)][0] = (int16_t)mvx;
-            L->cmv[SCAN8_0 + x + i + 8 * (y + j)][1] = (int16_t)mvy;
-        }
+    PCAMV_WAVE_SYNC();
+    FOR_CAND(i, w * h) {
+        int j = i / w, k = i - j * w, idx = SCAN8_0 + x + k + 8 * (y + j);
+        L->cmv[idx][0] = (int16_t)mvx; L->cmv[idx][1] = (int16_t)mvy;
+    }
+    PCAMV_WAVE_SYNC();
 }
 PCAMV_DEV void cache_ref_set(MBLocal *L, int x, int y, int w, int h, int ref)
 {
-    for (int j = 0; j < h; j++)
-        for (int i = 0; i < w; i++) L->cref[SCAN8_0 + x + i + 8 * (y + j)] = (int8_t)ref;
+    PCAMV_WAVE_SYNC();
+    FOR_CAND(i, w * h) { int j = i / w, k = i - j * w; L->cref[SCAN8_0 + x + k + 8 * (y + j)] = (int8_t)ref; }
+    PCAMV_WAVE_SYNC();
 }
 
 PCAMV_DEV void predict_from3(int ref, int refa, int refb, int refc, const int16_t *a, const int16_t *b, const int16_t *c, int mvp[2])
@@ -115,28 +119,22 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
     if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = F.mb_type[L->mb_xy - 1]; }
     if (mb_x < F.mb_w - 1 && mb_y > 0) { L->neighbour |= NB_TOPRIGHT; L->type_topright = F.mb_type[top + 1]; }
     if (mb_x > 0 && mb_y > 0) { L->neighbour |= NB_TOPLEFT; L->type_topleft = F.mb_type[top - 1]; }
-    for (int i = 0; i < 48; i++) { L->cref[i] = -2; L->cmv[i][0] = 0; L->cmv[i][1] = 0; }
+    PCAMV_WAVE_SYNC();
+    FOR_CAND(i, 48) { L->cref[i] = -2; L->cmv[i][0] = 0; L->cmv[i][1] = 0; }
+    PCAMV_WAVE_SYNC();
     int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
     int b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
     int t4 = (4 * (mb_y - 1) + 3) * s4 + 4 * mb_x, t8 = (2 * (mb_y - 1) + 1) * s8 + 2 * mb_x;
-    if (L->neighbour & NB_TOPLEFT) {
-        L->cref[SCAN8_0 - 1 - 8] = F.ref8[t8 - 1];
-        L->cmv[SCAN8_0 - 1 - 8][0] = F.mv[2 * (t4 - 1)]; L->cmv[SCAN8_0 - 1 - 8][1] = F.mv[2 * (t4 - 1) + 1];
+    /* the ten neighbouring 4x4 motion entries, one per lane: 0 top-left, 1..4 top, 5 top-right, 6..9 left */
+    FOR_CAND(i, 10) {
+        int ok, c8, m4, r8;
+        if (i == 0) { ok = L->neighbour & NB_TOPLEFT; c8 = SCAN8_0 - 1 - 8; m4 = t4 - 1; r8 = t8 - 1; }
+        else if (i <= 4) { ok = L->neighbour & NB_TOP; c8 = SCAN8_0 - 8 + (i - 1); m4 = t4 + (i - 1); r8 = t8 + ((i - 1) >> 1); }
+        else if (i == 5) { ok = L->neighbour & NB_TOPRIGHT; c8 = SCAN8_0 + 4 - 8; m4 = t4 + 4; r8 = t8 + 2; }
+        else { ok = L->neighbour & NB_LEFT; c8 = SCAN8_0 - 1 + 8 * (i - 6); m4 = b4 - 1 + (i - 6) * s4; r8 = b8 - 1 + ((i - 6) >> 1) * s8; }
+        if (ok) { L->cref[c8] = F.ref8[r8]; L->cmv[c8][0] = F.mv[2 * m4]; L->cmv[c8][1] = F.mv[2 * m4 + 1]; }
     }
-    if (L->neighbour & NB_TOP)
-        for (int i = 0; i < 4; i++) {
-            L->cref[SCAN8_0 - 8 + i] = F.ref8[t8 + (i >> 1)];
-            L->cmv[SCAN8_0 - 8 + i][0] = F.mv[2 * (t4 + i)]; L->cmv[SCAN8_0 - 8 + i][1] = F.mv[2 * (t4 + i) + 1];
-        }
-    if (L->neighbour & NB_TOPRIGHT) {
-        L->cref[SCAN8_0 + 4 - 8] = F.ref8[t8 + 2];
-        L->cmv[SCAN8_0 + 4 - 8][0] = F.mv[2 * (t4 + 4)]; L->cmv[SCAN8_0 + 4 - 8][1] = F.mv[2 * (t4 + 4) + 1];
-    }
-    if (L->neighbour & NB_LEFT)
-        for (int i = 0; i < 4; i++) {
-            L->cref[SCAN8_0 - 1 + 8 * i] = F.ref8[b8 - 1 + (i >> 1) * s8];
-            L->cmv[SCAN8_0 - 1 + 8 * i][0] = F.mv[2 * (b4 - 1 + i * s4)]; L->cmv[SCAN8_0 - 1 + 8 * i][1] = F.mv[2 * (b4 - 1 + i * s4) + 1];
-        }
+    PCAMV_WAVE_SYNC();
     int pm[2];
     predict_mv_pskip(L, pm);
     L->pskip_mv[0] = (int16_t)pm[0]; L->pskip_mv[1] = (int16_t)pm[1];

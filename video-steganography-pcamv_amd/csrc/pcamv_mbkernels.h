@@ -28,15 +28,22 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
     int *slots = L->slots;
     const int used = F.embed && L->i_type != PCAMV_P_SKIP;
     const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, used, slots);
+    pcamv_mb_t *r = &F.rec_mb[xy];
+    const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+    PCAMV_WAVE_SYNC();
+    /* the 16 per-4x4 entries of the record and of the frame's motion field (x264_macroblock_cache_save,
+     * common/macroblock.c:1254-1364), one per lane */
+    FOR_CAND(i, 16) {
+        int i8 = scan8_of(i);
+        r->ref[i] = L->cref[i8]; r->mv[i][0] = L->cmv[i8][0]; r->mv[i][1] = L->cmv[i8][1];
+        r->mv_stego[i][0] = r->mv_stego[i][1] = 0; r->inter_stego_cost[i] = 0;
+        int x = i & 3, y = i >> 2;
+        F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
+        F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
+    }
     if (PCAMV_LANE0) {
-        pcamv_mb_t *r = &F.rec_mb[xy];
         r->i_type = L->i_type; r->i_partition = L->i_partition; r->i_qp = F.qp;
         for (int i = 0; i < 4; i++) r->i_sub_partition[i] = L->i_type == PCAMV_P_8x8 ? L->sub_part[i] : PCAMV_D_L0_8x8;
-        for (int i = 0; i < 16; i++) {
-            int i8 = scan8_of(i);
-            r->ref[i] = L->cref[i8]; r->mv[i][0] = L->cmv[i8][0]; r->mv[i][1] = L->cmv[i8][1];
-            r->mv_stego[i][0] = r->mv_stego[i][1] = 0; r->inter_stego_cost[i] = 0;
-        }
         r->pskip_mv[0] = L->pskip_mv[0]; r->pskip_mv[1] = L->pskip_mv[1];
         if (L->i_type != PCAMV_P_SKIP) { r->mvr16[0] = F.mvr[2 * xy]; r->mvr16[1] = F.mvr[2 * xy + 1]; }
         else { r->mvr16[0] = r->mvr16[1] = 0; }
@@ -46,14 +53,7 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
             F.mvp_aux[(xy * 16 + slots[k]) * 2] = (int16_t)me->mvp[0];
             F.mvp_aux[(xy * 16 + slots[k]) * 2 + 1] = (int16_t)me->mvp[1];
         }
-        /* x264_macroblock_cache_save (common/macroblock.c:1254-1364): motion for the neighbours */
         F.mb_type[xy] = (int8_t)L->i_type;
-        int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
-        for (int y = 0; y < 4; y++)
-            for (int x = 0; x < 4; x++) {
-                F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
-                F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
-            }
         F.ref8[b8] = L->cref[scan8_of(0)]; F.ref8[b8 + 1] = L->cref[scan8_of(4)];
         F.ref8[b8 + s8] = L->cref[scan8_of(8)]; F.ref8[b8 + s8 + 1] = L->cref[scan8_of(12)];
     }
