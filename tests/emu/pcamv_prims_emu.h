@@ -209,6 +209,58 @@ static inline void prim_add_idct(const FrameDev &F, MBLocal *L, unsigned keep, i
         else if (mode == 1) { int v = (L->cdc[ch][ci] + 32) >> 6; for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) dst[y * 16 + x] = (uint8_t)clip3i(dst[y * 16 + x] + v, 0, 255); }
     }
 }
+/* transform stage of x264_macroblock_encode for an inter macroblock (encoder/macroblock.c:277-372, 696-753),
+ * scalar restatement with the reference's own loops (the GPU primitive does this lane-parallel) */
+static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
+{
+    prim_residual(F, L, 1, 1);
+    /* luma 8x8 / MB decimation (encoder/macroblock.c:696-753) */
+    unsigned keep = 0; int cbp = 0, decimate_mb = 0;
+    for (int i8 = 0; i8 < 4; i8++) {
+        int dec8 = 0, any = 0;
+        for (int i4 = 0; i4 < 4; i4++) {
+            int idx = i8 * 4 + i4;
+            if (L->blk_nz[idx]) { if (F.b_dct_decimate && dec8 < 6) dec8 += L->blk_score[idx]; any = 1; }
+        }
+        decimate_mb += dec8;
+        if (F.b_dct_decimate) { if (dec8 >= 4) cbp |= 1 << i8; }
+        else if (any) cbp |= 1 << i8;
+    }
+    if (F.b_dct_decimate && decimate_mb < 6) cbp = 0;
+    for (int i8 = 0; i8 < 4; i8++) if (cbp & (1 << i8)) keep |= 0xFu << (4 * i8);
+    L->cbp_luma = cbp;
+    /* chroma (encoder/macroblock.c:277-372) */
+    int cmode[2], any_ac = 0;
+    for (int ch = 0; ch < 2; ch++) {
+        int score = 0, nz_ac = 0, nz_dc = 0;
+        for (int i = 0; i < 4; i++) if (L->blk_nz[16 + ch * 4 + i]) { nz_ac = 1; if (F.b_dct_decimate) score += L->blk_score[16 + ch * 4 + i]; }
+        int dc[4];
+        { int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1;
+          for (int k = 0; k < 4; k++) {
+              int c = L->cdc[ch][k];
+              dc[k] = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+              nz_dc |= dc[k];
+          } }
+        int d0 = dc[0] + dc[1], d1 = dc[2] + dc[3], d2 = dc[0] - dc[1], d3 = dc[2] - dc[3];
+        int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        int r0 = (int16_t)((d0 + d1) * dmf >> -qbits), r1 = (int16_t)((d0 - d1) * dmf >> -qbits);
+        int r2 = (int16_t)((d2 + d3) * dmf >> -qbits), r3 = (int16_t)((d2 - d3) * dmf >> -qbits);
+        if ((F.b_dct_decimate && score < 7) || !nz_ac) {
+            if (!nz_dc) { cmode[ch] = 0; continue; }
+            cmode[ch] = 1;
+            L->cdc[ch][0] = (int16_t)r0; L->cdc[ch][1] = (int16_t)r1; L->cdc[ch][2] = (int16_t)r2; L->cdc[ch][3] = (int16_t)r3;
+        } else {
+            any_ac = 1; cmode[ch] = 2;
+            if (nz_dc) {
+                L->coef[16 + ch * 4 + 0][0] = (int16_t)r0; L->coef[16 + ch * 4 + 1][0] = (int16_t)r1;
+                L->coef[16 + ch * 4 + 2][0] = (int16_t)r2; L->coef[16 + ch * 4 + 3][0] = (int16_t)r3;
+            }
+        }
+    }
+    L->cbp_chroma = any_ac ? 2 : 0;
+    prim_add_idct(F, L, keep, cmode[0], cmode[1]);
+}
 static inline int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
 {
     (void)F; int s = 0;

@@ -375,70 +375,86 @@ __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L
     PCAMV_WAVE_SYNC();
 }
 
-/* forward 4x4 transform + quantisation + scan score + dequantisation, one 4x4 block per lane:
- * lanes 0..15 luma blocks (x264 block order), 16..19 U, 20..23 V. */
+/* forward 4x4 transform + quantisation + scan score + dequantisation of the lane's 4x4 block at
+ * (px,py) of the fenc/pred buffers (dct.c:122-170 sub4x4_dct, quant.c:33-109, 203-239).  d[] returns the
+ * DEquantised levels (all zero when nothing survives), *rawdc the unquantised DC (chroma: its DC goes
+ * through the 2x2 transform instead and d[0] is cleared before quantisation). */
+__device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+{
+    int t[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(L->pred + (py + y) * 16 + px);
+        int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
+        int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
+        int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
+        t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+        d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
+    }
+    *rawdc = d[0];
+    if (!is_l) d[0] = 0;
+    const int qp = is_l ? F.qp : F.chroma_qp;
+    /* the three position classes of the flat quantiser, picked once (no indexing of F inside the loops) */
+    const int mf0 = is_l ? F.q_mf[0][0] : F.q_mf[1][0], mf1 = is_l ? F.q_mf[0][1] : F.q_mf[1][1], mf2 = is_l ? F.q_mf[0][2] : F.q_mf[1][2];
+    const int bs0 = is_l ? F.q_bias[0][0] : F.q_bias[1][0], bs1 = is_l ? F.q_bias[0][1] : F.q_bias[1][1], bs2 = is_l ? F.q_bias[0][2] : F.q_bias[1][2];
+    const int dq0 = is_l ? F.dq_mf[0] : F.dq_mf_c[0], dq1 = is_l ? F.dq_mf[1] : F.dq_mf_c[1], dq2 = is_l ? F.dq_mf[2] : F.dq_mf_c[2];
+    /* quantise; build the non-zero mask in zigzag order and the "some |level| > 1" flag on the way */
+    unsigned zm = 0; int big = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of the zigzag) */
+        const int cls = (i & 1) + ((i >> 2) & 1), mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bias = cls == 0 ? bs0 : cls == 1 ? bs1 : bs2;
+        int c = d[i];
+        c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+        d[i] = (int16_t)c;
+        zm |= (unsigned)(c != 0) << zzinv[i];
+        big |= (unsigned)(c + 1) > 2u;
+    }
+    const int nz = zm != 0;
+    /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC
+     * ones for chroma): 9 as soon as a level exceeds 1, else the run-length table summed over the
+     * non-zero levels, walked from the top of the mask */
+    int score = 0;
+    if (nz) {
+        if (big) score = 9;
+        else {
+            unsigned m = zm; const int lo = is_l ? 0 : 1;
+            while (m) {
+                int pp = 31 - __builtin_clz(m);
+                m &= ~(1u << pp);
+                int pq = m ? 31 - __builtin_clz(m) : lo - 1;
+                score += (0x56Bu >> (2 * (pp - pq - 1))) & 3u;      /* decimate table[run] */
+            }
+        }
+        const int qbits = qp / 6 - 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int cls = (i & 1) + ((i >> 2) & 1), dqv = cls == 0 ? dq0 : cls == 1 ? dq1 : dq2;
+            d[i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
+        }
+    }
+    *nz_out = nz; *score_out = score;
+}
+/* one 4x4 block per lane into LDS (lanes 0..15 luma blocks in x264 block order, 16..19 U, 20..23 V):
+ * the form the P_SKIP probe's wave-uniform checks read */
 __device__ __forceinline__ void prim_residual(const FrameDev &F, MBLocal *L, int do_luma, int do_chroma)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     const bool is_l = lane < 16 && do_luma, is_c = lane >= 16 && lane < 24 && do_chroma;
-    int16_t d[16];
     if (is_l || is_c) {
-        int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+        int16_t d[16];
+        int ch = (lane - 16) >> 2, ci = (lane - 16) & 3, nz, score, rawdc;
         int px = is_l ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4;
         int py = is_l ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
-        int t[4][4];
+        residual_block(F, L, px, py, is_l, d, &nz, &score, &rawdc);
+        if (is_c) L->red[lane] = rawdc;
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(L->pred + (py + y) * 16 + px);
-            int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
-            int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
-            int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
-            t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
-            d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
-        }
-        if (is_c) { L->red[lane] = d[0]; d[0] = 0; }
-        const int qp = is_l ? F.qp : F.chroma_qp;
-        /* quantise; build the non-zero mask in zigzag order and the "some |level| > 1" flag on the way */
-        unsigned zm = 0; int big = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of zz4_tab) */
-            int cls = (i & 1) + ((i >> 2) & 1), mf = is_l ? F.q_mf[0][cls] : F.q_mf[1][cls], bias = is_l ? F.q_bias[0][cls] : F.q_bias[1][cls], c = d[i];
-            c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
-            d[i] = (int16_t)c;
-            zm |= (unsigned)(c != 0) << zzinv[i];
-            big |= (unsigned)(c + 1) > 2u;
-        }
-        const int nz = zm != 0;
-        /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC
-         * ones for chroma): 9 as soon as a level exceeds 1, else the run-length table summed over the
-         * non-zero levels, walked from the top of the mask */
-        int score = 0;
-        if (nz) {
-            if (big) score = 9;
-            else {
-                unsigned m = zm; const int lo = is_l ? 0 : 1;
-                while (m) {
-                    int pp = 31 - __builtin_clz(m);
-                    m &= ~(1u << pp);
-                    int pq = m ? 31 - __builtin_clz(m) : lo - 1;
-                    score += (0x56Bu >> (2 * (pp - pq - 1))) & 3u;      /* decimate_tab4[run] */
-                }
-            }
-            const int qbits = qp / 6 - 4;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                int cls = (i & 1) + ((i >> 2) & 1), dqv = is_l ? F.dq_mf[cls] : F.dq_mf_c[cls];
-                d[i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) *(uint32_t *)&L->coef[lane][i] = (uint32_t)(uint16_t)d[i] | (uint32_t)(uint16_t)d[i + 1] << 16;   /* all zero when !nz */
+        for (int i = 0; i < 16; i += 2) *(uint32_t *)&L->coef[lane][i] = (uint32_t)(uint16_t)d[i] | (uint32_t)(uint16_t)d[i + 1] << 16;
         L->blk_nz[lane] = nz; L->blk_score[lane] = score;
     }
     PCAMV_WAVE_SYNC();
@@ -507,6 +523,70 @@ __device__ __forceinline__ void prim_add_idct(const FrameDev &F, MBLocal *L, uns
         }
     }
     (void)F;
+    PCAMV_WAVE_SYNC();
+}
+/* 2x2 Hadamard over the four lanes of a quad: lane q gets v0 + s1 v1 + s2 v2 + s1 s2 v3 with
+ * s1 = -1 for q in {2,3}, s2 = -1 for q in {1,3} (dct2x2dc / idct_dequant_2x2_dc, encoder/macroblock.c:71-85) */
+__device__ __forceinline__ int quad_had2x2(int v, int q)
+{
+    int v0 = __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false), v1 = __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);
+    int v2 = __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false), v3 = __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);
+    int a = v0 + v1, b = v2 + v3, c = v0 - v1, e = v2 - v3;      /* d0, d1, d2, d3 of the reference */
+    return q == 0 ? a + b : q == 1 ? a - b : q == 2 ? c + e : c - e;
+}
+/* Transform stage of x264_macroblock_encode for an inter macroblock (encoder/macroblock.c:277-372,
+ * 696-753): residual transform + quantisation, luma 8x8 / macroblock decimation, chroma DC 2x2 and the
+ * chroma decimation rule, dequantisation, inverse transform added to the prediction in L->pred.
+ * One 4x4 block per lane (0..15 luma in x264 block order = quads of lanes are 8x8 blocks, 16..19 U,
+ * 20..23 V), levels stay in registers, every decision is a quad / row DPP reduction:
+ *   - the reference's saturating `if (dec8 < 6) dec8 += score` only ever compares against 4 and 6, so
+ *     plain sums decide identically. */
+__device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    const bool is_l = lane < 16, is_c = lane >= 16 && lane < 24;
+    const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+    const int px = is_l ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4;
+    const int py = is_l ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
+    int16_t d[16];
+    int nz = 0, score = 0, rawdc = 0;
+    if (is_l || is_c) residual_block(F, L, px, py, is_l, d, &nz, &score, &rawdc);
+    /* luma: 8x8 sums over quads, macroblock sum over the row of 16 lanes */
+    const int sc = (nz && F.b_dct_decimate) ? score : 0;
+    int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8);
+    int any8 = nz | dpp_qp1(nz); any8 |= dpp_qp2(any8);
+    int row = q8 + dpp_hmir(q8); row += dpp_mir(row);            /* the four quad sums of the 16-lane row together */
+    bool keep = F.b_dct_decimate ? (q8 >= 4 && row >= 6) : any8 != 0;
+    /* chroma: per plane (quad) AC score, DC 2x2 transform, quantisation, dequantisation */
+    const int cdc = quad_had2x2(rawdc, lane & 3);
+    int dcq;
+    { const int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1;
+      dcq = cdc > 0 ? ((bias + cdc) * mf >> 16) : -((bias - cdc) * mf >> 16); }
+    int nzdc = dcq != 0; nzdc |= dpp_qp1(nzdc); nzdc |= dpp_qp2(nzdc);
+    int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
+    if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+    const int rdc = (int16_t)(quad_had2x2(dcq, lane & 3) * dmf >> -qbits);
+    const int cmode = (q8 < 7 && F.b_dct_decimate) || !any8 ? (nzdc ? 1 : 0) : 2;     /* on chroma lanes q8 / any8 are the plane's */
+    const unsigned long long keep_mask = __ballot(is_l && keep), ac_mask = __ballot(is_c && cmode == 2);
+    uint8_t *dst = L->pred + py * 16 + px;
+    if (is_l) {
+        if (keep && nz) idct4x4_add(dst, d);
+    } else if (is_c) {
+        if (cmode == 2) { if (nzdc) d[0] = (int16_t)rdc; idct4x4_add(dst, d); }
+        else if (cmode == 1) {
+            const int v = (rdc + 32) >> 6;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t p = lds4(dst + y * 16), o = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((p >> (8 * x)) & 255) + v, 0, 255) << (8 * x);
+                sts4(dst + y * 16, o);
+            }
+        }
+    }
+    L->cbp_luma = (int)((keep_mask & 1) | ((keep_mask >> 3) & 2) | ((keep_mask >> 6) & 4) | ((keep_mask >> 9) & 8));
+    L->cbp_chroma = ac_mask ? 2 : 0;
     PCAMV_WAVE_SYNC();
 }
 __device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
