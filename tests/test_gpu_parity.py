@@ -183,3 +183,68 @@ def test_open_rejects_unsupported(pc):
     p = pc.param_default(170, 144)
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)
+
+
+def test_schedules_agree(pc):
+    """the persistent dataflow launch and the per-anti-diagonal launches are the same computation"""
+    import os
+    from pcamv_amd.synth import make_clip
+    W, H = 352, 288
+    clip = make_clip(W, H, 2, seed=5, static_cols=32)
+    out = {}
+    for sched in ("diag", "flow"):
+        if sched == "diag":
+            os.environ["PCAMV_SCHED"] = "diag"
+        try:
+            enc = pc.Encoder(_params(pc, W, H, pc.ME_NAMES["umh"], 5, 0x10, pc.level_mv_range(W, H)))
+        finally:
+            os.environ.pop("PCAMV_SCHED", None)
+        enc.set_ref(*clip[0]); enc.upload_fenc(*clip[1])
+        mbs, rec = enc.analyse_pframe(27, embed=1)
+        emb = enc.embed_pframe(0.5)
+        out[sched] = (mbs, rec, emb)
+        enc.close()
+    a, b = out["diag"], out["flow"]
+    for f in a[0].dtype.names:
+        assert np.array_equal(a[0][f], b[0][f]), f
+    for x, y in zip(a[1], b[1]):
+        assert np.array_equal(x, y)
+    for k in ("cover", "rho", "message", "stego", "flip"):
+        assert np.array_equal(a[2][k], b[2][k]), k
+
+
+def test_1080p_batch_step_matches_oracle(pc):
+    """BASELINE's size through the batch API (device-resident planes, several closed GOPs advanced by one
+    dataflow launch): every GOP's record, embedding vectors and extracted payload against the oracle."""
+    import torch
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H = 1920, 1088
+    clip = make_clip(W, H, 3, seed=13)
+    dev = torch.device("cuda", 0)
+    d = [[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip]
+    mvr = pc.level_mv_range(W, H)
+    p = _params(pc, W, H, pc.ME_NAMES["umh"], 5, 0x10, mvr)
+    encs = [pc.Encoder(p) for _ in range(2)]
+    batch = pc.Batch(encs)
+    for g, enc in enumerate(encs):       # GOP g: reference = frame g, source = frame g + 1
+        enc.set_ref_device(d[g][0].data_ptr(), d[g][1].data_ptr(), d[g][2].data_ptr(), None, None)
+        enc.set_fenc_device(d[g + 1][0].data_ptr(), d[g + 1][1].data_ptr(), d[g + 1][2].data_ptr())
+    batch.step(26, 0.5, 0)
+    for g, enc in enumerate(encs):
+        mbs, emb = enc.fetch_results(want_embed=True)
+        o = orc.Oracle(orc.make_params(W, H, me="umh", subme=5, mv_range=mvr))   # own message stream, like each context
+        o.set_ref(*clip[g]); o.set_fenc(*clip[g + 1])
+        mbs_o, _ = o.analyse_pframe(26, 1)
+        for f in mbs.dtype.names:
+            assert np.array_equal(mbs[f], mbs_o[f]), f"GOP {g}: {f}"
+        emb_o = o.embed_pframe(mbs_o, 0.5)
+        assert (emb["n"], emb["m"], emb["stc_ok"], emb["num_flip"]) == (emb_o["n"], emb_o["m"], emb_o["stc_ok"], emb_o["num_flip"])
+        for k in ("cover", "rho", "message", "stego", "flip"):
+            assert np.array_equal(emb[k], emb_o[k]), f"GOP {g}: {k}"
+        final = enc.final_mvs(mbs)
+        assert np.array_equal(pc.stc_extract(helpers.carrier_lsbs(final), emb["m"]), emb["message"]), "BER != 0"
+        o.close()
+    batch.close()
+    for enc in encs:
+        enc.close()
