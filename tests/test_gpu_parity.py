@@ -29,7 +29,7 @@ def _params(pc, W, H, me, subme, inter, mv_range, me_range=16, tscale=256):
     return p
 
 
-GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
+GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
 
 
 @pytest.mark.parametrize("name", GPU_FIXTURES)

@@ -175,7 +175,7 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     *out = NULL;
     if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
     if (p->i_subpel_refine < 1 || p->i_subpel_refine > 5) return PCAMV_EUNSUP;   /* >=6 needs CABAC-size RDO */
-    if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_UMH) return PCAMV_EUNSUP; /* ESA/TESA: next */
+    if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_ESA) return PCAMV_EUNSUP; /* TESA keeps candidates by ADS thresholds: needs the integral image, next */
     if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCAMV_ENODEV;

@@ -346,6 +346,25 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
         } while (++i < i_me_range);
     } else if (F.me_method == PCAMV_ME_HEX) {
         hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+    } else if (F.me_method == PCAMV_ME_ESA) {
+        /* exhaustive search (me.c:489-622).  The reference walks the window row by row, drops
+         * positions whose sum-of-block-DC difference (ADS, a lower bound of the SAD) plus MV bits
+         * cannot beat the running best, and tests the rest in raster order with strict <.  A dropped
+         * position could never have won, so the first minimum over ALL positions of the same window
+         * in the same order is the same result; no integral image is needed here.  The window is the
+         * reference's: width rounded as (max_x - min_x + 3) & ~3 columns starting at min_x. */
+        const int min_x = imax(bmx - i_me_range, mv_x_min), min_y = imax(bmy - i_me_range, mv_y_min);
+        const int max_x = imin(bmx + i_me_range, mv_x_max), max_y = imin(bmy + i_me_range, mv_y_max);
+        const int width = (max_x - min_x + 3) & ~3;
+        const int total = width > 0 && max_y >= min_y ? width * (max_y - min_y + 1) : 0;
+        for (int base = 0; base < total; base += 64) {
+            const int n = imin(64, total - base);
+            FOR_CAND(c, n) {
+                int g = base + c, ry = g / width, rx = g - ry * width;
+                L->cxy[c] = CAND_PACK((min_x + rx) * 4, (min_y + ry) * 4);
+            }
+            fpel_fold(F, L, me, bmx, bmy, bcost, n);
+        }
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
 #define SAD_THRESH(v) (bcost < ((v) >> size_shift_of(ip)))
