@@ -128,6 +128,14 @@ def main():
     # k_search_diag:  one launch = one anti-diagonal of every GOP in flight
     mbs_per_launch = args.gops * n_mb / (1 if dom == "k_analyse_flow" else n_diag)
     achieved = B_SEARCH * mbs_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM-side traffic of the dominant kernel: PMC FETCH_SIZE + WRITE_SIZE of this same command, collected in
+    # separate rocprofv3 passes (tools/dbg/pmc_traffic.sh) and committed under profiles/; scaled to one launch
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if dom == "k_analyse_flow" and os.path.exists(tfile):
+        with open(tfile) as fh:
+            tj = json.load(fh)["k_analyse_flow_bytes_per_mb"]
+        traffic = (tj["fetch_raw"] + tj["write"]) * mbs_per_launch
     out = {
         "metric": "1080p macroblocks/s (embed on)", "value": value, "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -140,7 +148,7 @@ def main():
         "carriers_per_frame": int(emb["n"]), "bits_per_frame": int(emb["m"]),
         "hbm_algorithmic_GBps_whole_path": 5888.0 * value / 1e9,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None,
+                     "frac": achieved / 8000.0, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH},
     }
 
