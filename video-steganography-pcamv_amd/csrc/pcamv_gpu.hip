@@ -146,8 +146,15 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     b->sched_flow = !(sched && !strcmp(sched, "diag")) && F.n_mb <= 65535 && n <= 65535;
     if (e == hipSuccess && b->sched_flow) {
         const size_t total = (size_t)n * F.n_mb;
-        e = dalloc(&b->d_flow, 16 + 2 * total);
-        b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + 16; b->fl.dep = (int *)(b->d_flow + 16 + total);
+        e = dalloc(&b->d_flow, 32 + 2 * total);
+        b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + 32; b->fl.dep = (int *)(b->d_flow + 32 + total);
+        const char *aff = getenv("PCAMV_FLOW_AFFINITY");
+        b->fl.nq = (aff && !strcmp(aff, "0")) || n < 8 ? 1 : 8;
+        unsigned qb = 0;
+        for (int q = 0; q < 8; q++) {
+            unsigned ng = q < b->fl.nq ? ((unsigned)n + (unsigned)(b->fl.nq - 1 - q)) / (unsigned)b->fl.nq : 0u;
+            b->fl.qbase[q] = qb; b->fl.qcount[q] = ng * (unsigned)F.n_mb; qb += b->fl.qcount[q];
+        }
         b->fl.total = (unsigned)total; b->fl.spin_limit = 4u << 20;
         b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1;
         int per_cu = 0, n_cu = 0;
@@ -366,7 +373,7 @@ static int flow_check(pcamv_batch *b)
 {
     if (!b || !b->sched_flow) return 0;
     unsigned bad = 0;
-    HIPCHKB(b, hipMemcpy(&bad, b->fl.ctr + 2, sizeof(bad), hipMemcpyDeviceToHost));
+    HIPCHKB(b, hipMemcpy(&bad, b->fl.ctr + 16, sizeof(bad), hipMemcpyDeviceToHost));
     if (bad) return bfail(b, PCAMV_EHIP, "k_analyse_flow: queue wait timed out (results of the last step are incomplete)");
     return 0;
 }

@@ -149,11 +149,12 @@ __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
  * entries are appended by waves that are running, and the dependency graph always has a ready node
  * until everything is done.  Spins are bounded; a timeout raises ctr[2] and every wave drains. */
 struct FlowDev {
-    unsigned *ctr;            /* [0] pop index, [1] append index, [2] error flag */
-    unsigned *queue;          /* total entries; 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
+    unsigned *ctr;            /* [0..7] pop index of queue x, [8..15] append index of queue x, [16] error flag */
+    unsigned *queue;          /* total entries, queue x at [qbase[x], qbase[x] + qcount[x]); 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
     int *dep;                 /* [n_gop * n_mb] dependencies still open */
     unsigned total, spin_limit;
-    int n_gop, n_mb, mb_w, mb_h, fused;
+    unsigned qbase[8], qcount[8];
+    int n_gop, n_mb, mb_w, mb_h, fused, nq;      /* nq = 8: GOP g lives in queue g & 7 (XCD affinity); nq = 1: one queue */
 };
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -163,16 +164,21 @@ __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
     if (i >= fl.total) return;
     int xy = (int)(i % (unsigned)fl.n_mb), x = xy % fl.mb_w, y = xy / fl.mb_w;
     fl.dep[i] = (x > 0) + (y > 0);
-    fl.queue[i] = i < (unsigned)fl.n_gop ? (i << 16) + 1u : 0u;       /* macroblock 0 of every GOP is ready */
-    if (i == 0) { fl.ctr[0] = 0; fl.ctr[1] = (unsigned)fl.n_gop; fl.ctr[2] = 0; }
+    /* word i of the queue array is entry k of queue q; the first ngop(q) entries of each queue start out
+     * published: macroblock 0 of the GOPs k * nq + q */
+    int q = 0;
+    while (q + 1 < fl.nq && i >= fl.qbase[q + 1]) q++;
+    const unsigned k = i - fl.qbase[q], ngop_q = fl.qcount[q] / (unsigned)fl.n_mb;
+    fl.queue[i] = k < ngop_q ? ((k * (unsigned)fl.nq + (unsigned)q) << 16) + 1u : 0u;
+    if (i < 17) fl.ctr[i] = (i >= 8 && i < 16) ? fl.qcount[i - 8] / (unsigned)fl.n_mb : 0u;     /* heads 0, tails = GOPs of the queue, error 0 */
 }
 
 __device__ __forceinline__ unsigned flow_bcast(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ void flow_done_one(const FlowDev &fl, int slot, unsigned item)
+__device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot, unsigned item)
 {
     if (__hip_atomic_fetch_sub(&fl.dep[slot], 1, RLX_AGENT) == 1) {
-        unsigned t = __hip_atomic_fetch_add(&fl.ctr[1], 1u, RLX_AGENT);
-        __hip_atomic_store(&fl.queue[t], item, RLX_AGENT);
+        unsigned t = __hip_atomic_fetch_add(&fl.ctr[8 + q], 1u, RLX_AGENT);
+        __hip_atomic_store(&fl.queue[fl.qbase[q] + t], item, RLX_AGENT);
     }
 }
 
@@ -184,23 +190,34 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
     __shared__ MBLocal L;
     __shared__ Analysis A;
     const int lane = LANE();
+    /* home queue = this wave's XCD (speed only: the GOPs of one queue are then searched through one L2
+     * instead of being replicated in all eight); a wave whose queue is handed out moves on to the others */
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    int home = (int)(xcc & 7u) & (fl.nq - 1), tried = 0;
     for (;;) {
         unsigned idx = 0;
-        if (lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[0], 1u, RLX_AGENT);
+        if (lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
         idx = flow_bcast(idx);
-        if (idx >= fl.total) break;                        /* every macroblock has been handed out */
+        if (idx >= fl.qcount[home]) {                      /* this queue is handed out: next one, or done */
+            if (++tried >= fl.nq) break;
+            home = (home + 1) & (fl.nq - 1);
+            continue;
+        }
+        tried = 0;
+        const unsigned slot = fl.qbase[home] + idx;
         unsigned item = 0;
         for (unsigned spins = 0;; spins++) {
             unsigned v = 0;
-            if (lane == 0) v = __hip_atomic_load(&fl.queue[idx], RLX_AGENT);
+            if (lane == 0) v = __hip_atomic_load(&fl.queue[slot], RLX_AGENT);
             item = flow_bcast(v);
             if (item) break;
             unsigned bad = 0;
-            if ((spins & 255u) == 255u) { if (lane == 0) bad = __hip_atomic_load(&fl.ctr[2], RLX_AGENT); bad = flow_bcast(bad); }
+            if ((spins & 255u) == 255u) { if (lane == 0) bad = __hip_atomic_load(&fl.ctr[16], RLX_AGENT); bad = flow_bcast(bad); }
             if (bad || spins >= fl.spin_limit) break;
             if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
         }
-        if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[2], 1u, RLX_AGENT); break; }
+        if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[16], 1u, RLX_AGENT); break; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         /* drop this CU's stale L1 lines of the neighbours' motion */
         const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
         const FrameDev F = Fs[g];
@@ -211,11 +228,11 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            const int base = g * fl.n_mb;
-            if (x + 1 < fl.mb_w) flow_done_one(fl, base + xy + 1, item + 1u);
+            const int base = g * fl.n_mb, q = g & (fl.nq - 1);
+            if (x + 1 < fl.mb_w) flow_done_one(fl, q, base + xy + 1, item + 1u);
             if (y + 1 < fl.mb_h) {
-                if (x >= 1) flow_done_one(fl, base + xy + fl.mb_w - 1, item + (unsigned)fl.mb_w - 1u);
-                if (x == fl.mb_w - 1) flow_done_one(fl, base + xy + fl.mb_w, item + (unsigned)fl.mb_w);
+                if (x >= 1) flow_done_one(fl, q, base + xy + fl.mb_w - 1, item + (unsigned)fl.mb_w - 1u);
+                if (x == fl.mb_w - 1) flow_done_one(fl, q, base + xy + fl.mb_w, item + (unsigned)fl.mb_w);
             }
         }
         if (fl.fused) mbk_rca_encode(F, &L, &A, xy);
