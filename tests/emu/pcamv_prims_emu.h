@@ -115,8 +115,10 @@ static inline void emu_pred_px(const FrameDev &F, MBLocal *L, int x, int y, int 
     const uint8_t *r = emu_qpel(F, tmp, &st, L->mb_x * 16 + x, L->mb_y * 16 + y, mvx, mvy, 1, 1);
     L->pred[y * 16 + x] = r[0];
 }
-static inline void prim_predict_mb(const FrameDev &F, MBLocal *L)
+static inline void prim_win_load(const FrameDev &F, MBLocal *L, int bmx, int bmy) { (void)F; (void)L; (void)bmx; (void)bmy; }   /* the scalar prims read the planes directly */
+static inline void prim_predict_mb(const FrameDev &F, MBLocal *L, int win = 0)
 {
+    (void)win;
     for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) {
         int i8 = SCAN8_0 + (x >> 2) + 8 * (y >> 2);
         emu_pred_px(F, L, x, y, clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]));

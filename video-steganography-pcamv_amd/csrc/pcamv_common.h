@@ -112,6 +112,11 @@ struct MBLocal {
     int mvc16[9][2];               /* candidate MVs of the 16x16 search */
     int nbc[12];                   /* neighbourhood costs of the RCA step */
     int slots[16];
+    /* reference window of the RCA step of a 16x16 macroblock: every MV it touches lies within +-3 quarter
+     * pels of the decided one, so 4 luma planes of 24 x 20 and 2 chroma planes of 16 x 12 bytes hold all
+     * the reference pixels of its re-encodes and nine-point lists */
+    uint32_t win[(4 * 480 + 2 * 192) / 4];
+    int win_x0, win_y0, win_cx0, win_cy0;     /* plane coordinates (padded-plane origin) of the window's first byte */
 };
 #define NB_LEFT 1
 #define NB_TOP 2
@@ -132,6 +137,13 @@ struct MBLocal {
 #define EV_FPEL 4      /* promise: every candidate is full-pel (single-plane fetch) */
 #define EV_NOMV 8      /* do not add the MV bit cost */
 #define EV_PROBE 16    /* chroma terms go to ccost[64 + c] (U) and ccost[128 + c] (V) instead of being added */
+#define EV_WIN 32      /* every candidate lies in the LDS reference window (L->win): no global loads */
+#define WIN_LW 24      /* luma window: bytes per row, rows, bytes per plane */
+#define WIN_LH 20
+#define WIN_LP (WIN_LW * WIN_LH)
+#define WIN_CW 16      /* chroma window */
+#define WIN_CH 12
+#define WIN_CP (WIN_CW * WIN_CH)
 struct EvalRes { int cost, idx; };
 /* lane-parallel generation of a candidate list: the body runs once per candidate index c < n (n <= 64) */
 #ifdef PCAMV_HOST_EMU

@@ -438,7 +438,7 @@ PCAMV_DEV void me_refine_qpel(const FrameDev &F, MBLocal *L, MEState *me)
 
 /* ---------------------------------------------------------------- macroblock (re-)encode */
 /* sequential-equivalent decimation of a 4x4 scan: done per block by prim_residual (blk_score) */
-PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L)
+PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L, int win = 0)
 {
     if (L->i_type == PCAMV_P_SKIP) {
         if (!L->b_skip_mc) {
@@ -449,7 +449,7 @@ PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L)
         L->cbp_luma = L->cbp_chroma = 0;
         return;
     }
-    if (!L->b_skip_mc) prim_predict_mb(F, L);
+    if (!L->b_skip_mc) prim_predict_mb(F, L, win);
     prim_mb_transform(F, L);
 }
 
@@ -630,9 +630,9 @@ PCAMV_DEV int d_nb_y(int i) { return nib64(0x120201210ull, i) - 1; }
 /* nine neighbourhood costs around (cx,cy) on the current reconstruction (MV_SATD_FDEC_IH: metric of
  * the reconstructed block against the reference at the candidate MV + MV bits + chroma for
  * partitions >= 8x8), one list; returns the minimum, the centre's cost in *last */
-PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, const uint8_t *enc, int cx, int cy, int nb_cost, int *last)
+PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, const uint8_t *enc, int cx, int cy, int nb_cost, int *last, int win)
 {
-    const int flags = (F.subme > 1 ? EV_SATD : 0) | ((F.b_chroma_me && me->i_pixel <= PIX_8x8) ? EV_CHROMA : 0);
+    const int flags = (F.subme > 1 ? EV_SATD : 0) | ((F.b_chroma_me && me->i_pixel <= PIX_8x8) ? EV_CHROMA : 0) | (win ? EV_WIN : 0);
     FOR_CAND(c, 9) L->cxy[c] = CAND_PACK(cx + d_nb_x(c), cy + d_nb_y(c));
     EvalRes r = eval_cands(F, L, me, enc, 9, flags);
     if (nb_cost) { FOR_CAND(c, 9) L->nbc[c] = L->ccost[c]; PCAMV_WAVE_SYNC(); }
@@ -642,14 +642,14 @@ PCAMV_DEV int rca_nine(const FrameDev &F, MBLocal *L, MEState *me, const uint8_t
 
 /* have_base: L->recb0 already holds the reconstruction of the macroblock as decided (the first re-encode
  * of x264_ih_get_mv_cost is the same for every carrier of the macroblock, and is its pass-1 output) */
-PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *me, int *m_x, int *m_y, int have_base)
+PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *me, int *m_x, int *m_y, int have_base, int win = 0)
 {
     const float beta1 = 1.4, beta2 = 4;
     int bmx = me->mv[0], bmy = me->mv[1];
     int cost = 0, min_cost;
     int b_1_neighbor = 0, b_error_pos = 0;
     if (!have_base) { update_cache(L, a); mb_encode(F, L); prim_copy_pred(L, L->recb0); }
-    min_cost = rca_nine(F, L, me, L->recb0, bmx, bmy, 1, &cost);
+    min_cost = rca_nine(F, L, me, L->recb0, bmx, bmy, 1, &cost, win);
     me->cost_rec = L->nbc[8];
     const int want_optimal = !(min_cost < me->cost_rec);
     min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
@@ -657,8 +657,8 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
     for (int ii = 0; ii < 12; ii++) {
         int bx1 = bmx + d_mv_x(ii), by1 = bmy + d_mv_y(ii);
         me->mv[0] = bx1; me->mv[1] = by1;
-        update_cache(L, a); mb_encode(F, L); prim_copy_pred(L, L->recb);
-        int min1 = rca_nine(F, L, me, L->recb, bx1, by1, 0, &cost);
+        update_cache(L, a); mb_encode(F, L, win); prim_copy_pred(L, L->recb);
+        int min1 = rca_nine(F, L, me, L->recb, bx1, by1, 0, &cost, win);
         int is_opt = (min1 == cost);
         if (is_opt == want_optimal && cost < min_cost) { min_cost = cost; *m_x = d_mv_x(ii); *m_y = d_mv_y(ii); ii_best = ii; }
         if (ii == 3 && min_cost != PCAMV_COST_MAX) break;

@@ -108,11 +108,18 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
     prim_store_rec(F, L);
     if (F.rec_mb[xy].used && n > 0) {
         prim_copy_pred(L, L->recb0);
+        /* a 16x16 macroblock whose RCA neighbourhood (+-3 quarter pels) needs no MV clipping reads its
+         * reference pixels from an LDS window loaded once, instead of ~30 scattered global fetches */
+        int win = 0;
+        if (L->i_type == PCAMV_P_L0 && L->i_partition == PCAMV_D_16x16) {
+            const int bx = a->me16x16.mv[0], by = a->me16x16.mv[1];
+            if (bx - 3 >= L->mv_min[0] && bx + 3 <= L->mv_max[0] && by - 3 >= L->mv_min[1] && by + 3 <= L->mv_max[1]) { prim_win_load(F, L, bx, by); win = 1; }
+        }
         for (int k = 0; k < n; k++) {
             MEState *me = slot_me(L, a, slots[k]);
             int dx = 0, dy = 0;
             const int bx = me->mv[0], by = me->mv[1];
-            const int cost = rca_mv_cost(F, L, a, me, &dx, &dy, 1);
+            const int cost = rca_mv_cost(F, L, a, me, &dx, &dy, 1, win);
             if (PCAMV_LANE0) {
                 pcamv_mb_t *r = &F.rec_mb[xy];
                 r->mv_stego[slots[k]][0] = (int16_t)(bx + dx); r->mv_stego[slots[k]][1] = (int16_t)(by + dy);

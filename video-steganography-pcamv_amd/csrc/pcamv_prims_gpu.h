@@ -163,6 +163,59 @@ __device__ __forceinline__ void chroma_block4(gp8 cb, uint32_t cstride, uint32_t
     }
 }
 
+/* ---- LDS reference window (RCA of a 16x16 macroblock) ---- */
+/* 4 bytes at byte offset b of the window: two aligned words + v_alignbit (LDS wants natural alignment) */
+__device__ __forceinline__ uint32_t wld4(const MBLocal *L, int b)
+{
+    const uint32_t *w = L->win + (b >> 2);
+    return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)(b & 3) * 8u);
+}
+/* load the window around the decided MV (bmx,bmy): luma planes from (x0,y0) = MB origin + ((mv - 3) >> 2),
+ * chroma from ((mv - 3) >> 3); coalesced row segments, one dword per lane and step */
+__device__ __forceinline__ void prim_win_load(const FrameDev &F, MBLocal *L, int bmx, int bmy)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    const int x0 = L->mb_x * 16 + PCAMV_PAD + ((bmx - 3) >> 2), y0 = L->mb_y * 16 + PCAMV_PAD + ((bmy - 3) >> 2);
+    const int cx0 = L->mb_x * 8 + PCAMV_CPAD + ((bmx - 3) >> 3), cy0 = L->mb_y * 8 + PCAMV_CPAD + ((bmy - 3) >> 3);
+    const gp8 lb = (gp8)F.luma_base, cb = (gp8)F.chroma_base[0];
+    const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size, cstride = (uint32_t)F.cstride, cps = (uint32_t)F.cplane_size;
+    for (int i = lane; i < 4 * WIN_LH * (WIN_LW / 4); i += 64) {
+        const int pl = i / (WIN_LH * (WIN_LW / 4)), r = (i / (WIN_LW / 4)) % WIN_LH, c = i % (WIN_LW / 4);
+        L->win[i] = gld4(lb, (uint32_t)pl * psz + (uint32_t)(y0 + r) * stride + (uint32_t)(x0 + 4 * c));
+    }
+    for (int i = lane; i < 2 * WIN_CH * (WIN_CW / 4); i += 64) {
+        const int pl = i / (WIN_CH * (WIN_CW / 4)), r = (i / (WIN_CW / 4)) % WIN_CH, c = i % (WIN_CW / 4);
+        L->win[4 * WIN_LP / 4 + i] = gld4(cb, (uint32_t)pl * cps + (uint32_t)(cy0 + r) * cstride + (uint32_t)(cx0 + 4 * c));
+    }
+    if (lane == 0) { L->win_x0 = x0; L->win_y0 = y0; L->win_cx0 = cx0; L->win_cy0 = cy0; }
+    PCAMV_WAVE_SYNC();
+}
+/* chroma_block4 out of the window: b = byte offset of the block's first reference pixel */
+__device__ __forceinline__ void chroma_block4_win(const MBLocal *L, int b, int mvx, int mvy, uint32_t r[4])
+{
+    const int dx = mvx & 7, dy = mvy & 7;
+    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    const uint32_t sh = (uint32_t)(b & 3) * 8u;
+    uint32_t w[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t *p = L->win + ((b + k * WIN_CW) >> 2);
+        const uint32_t lo = __builtin_amdgcn_alignbit(p[1], p[0], sh), hi = __builtin_amdgcn_alignbit(p[2], p[1], sh);
+        w[k][0] = lo; w[k][1] = __builtin_amdgcn_alignbit(hi, lo, 8); w[k][2] = __builtin_amdgcn_alignbit(hi, lo, 16); w[k][3] = __builtin_amdgcn_alignbit(hi, lo, 24);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t px = __builtin_amdgcn_perm(w[k + 1][i], w[k][i], 0x05040100u);
+            o |= (__builtin_amdgcn_udot4(px, W, 32u, false) >> 6) << (8 * i);
+        }
+        r[k] = o;
+    }
+}
+
 /* Costs of the n <= 64 candidates listed in L->cxy for the block (ip at xoff,yoff) against the source
  * rows in enc (LDS: L->fenc or L->recb).
  *   luma:   lane = slot * nblk + blk, 64/nblk candidates per pass, passes back to back; each lane
@@ -200,7 +253,18 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
             const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
             const uint32_t o = rowbase + (uint32_t)((mvy >> 2) * (int)stride + (mvx >> 2));
             uint32_t r[4];
-            if (flags & EV_FPEL) {
+            if (flags & EV_WIN) {
+                const int dx = mvx & 3, dy = mvy & 3;
+                const int wb = (L->mb_y * 16 + py + PCAMV_PAD + (mvy >> 2) - L->win_y0) * WIN_LW + (L->mb_x * 16 + px + PCAMV_PAD + (mvx >> 2) - L->win_x0);
+                const int ba = wb + ((dx != 0) + 2 * (dy == 2)) * WIN_LP + (dy == 3 ? WIN_LW : 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = wld4(L, ba + k * WIN_LW);
+                if ((dx | dy) & 1) {
+                    const int bb = wb + (dy ? (2 + (dx == 2)) * WIN_LP : 0) + (dx == 3);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) r[k] = avg4(r[k], wld4(L, bb + k * WIN_LW));
+                }
+            } else if (flags & EV_FPEL) {
                 r[0] = gld4(lb, o); r[1] = gld4(lb1, o); r[2] = gld4(lb2, o); r[3] = gld4(lb3, o);
             } else {
                 /* get_ref (mc.c:194-243): plane pair by the quarter-pel phase, in arithmetic form of hpel_ref0/1 */
@@ -245,7 +309,11 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
             const bool act = c < n && xy != CAND_NONE;
             const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
             uint32_t r[4];
-            chroma_block4(cb, cstride, rowbase + (uint32_t)((mvy >> 3) * (int)cstride + (mvx >> 3)), mvx, mvy, r);
+            if (flags & EV_WIN)
+                chroma_block4_win(L, 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + py + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW
+                                         + (L->mb_x * 8 + px + PCAMV_CPAD + (mvx >> 3) - L->win_cx0), mvx, mvy, r);
+            else
+                chroma_block4(cb, cstride, rowbase + (uint32_t)((mvy >> 3) * (int)cstride + (mvx >> 3)), mvx, mvy, r);
             int v;
             if (satd) v = satd4x4_half(ec, r);
             else {
@@ -345,18 +413,33 @@ __device__ __forceinline__ uint32_t chroma_px2(const FrameDev &F, int plane, int
     const uint32_t p1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b, a, 0x06050201u), W, 32u, false) >> 6;
     return p0 | p1 << 8;
 }
-__device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L)
+__device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L, int win)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3, i8 = SCAN8_0 + c4 + 8 * (row >> 2);
       int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
-      sts4(L->pred + row * 16 + 4 * c4, luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy)); }
+      uint32_t v;
+      if (win) {
+          const int dx = mvx & 3, dy = mvy & 3;
+          const int wb = (L->mb_y * 16 + row + PCAMV_PAD + (mvy >> 2) - L->win_y0) * WIN_LW + (L->mb_x * 16 + 4 * c4 + PCAMV_PAD + (mvx >> 2) - L->win_x0);
+          v = wld4(L, wb + ((dx != 0) + 2 * (dy == 2)) * WIN_LP + (dy == 3 ? WIN_LW : 0));
+          if ((dx | dy) & 1) v = avg4(v, wld4(L, wb + (dy ? (2 + (dx == 2)) * WIN_LP : 0) + (dx == 3)));
+      } else v = luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
+      sts4(L->pred + row * 16 + 4 * c4, v); }
     {   /* chroma: every lane two pixels (one 2x2 chroma block row carries one luma 4x4's MV) */
         int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3;
         int i8 = SCAN8_0 + c2 + 8 * (row >> 1);
         int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
-        uint32_t t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
+        uint32_t t;
+        if (win) {
+            const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + row + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
+            const int dx = mvx & 7, dy = mvy & 7;
+            const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+            const uint32_t a = wld4(L, b), bb = wld4(L, b + WIN_CW);
+            t = (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x05040100u), W, 32u, false) >> 6)
+              | (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x06050201u), W, 32u, false) >> 6) << 8;
+        } else t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
         *(uint16_t *)(L->pred + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
     }
     PCAMV_WAVE_SYNC();
