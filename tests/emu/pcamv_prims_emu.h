@@ -77,13 +77,14 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
     for (int c = 0; c < n; c++) {
         if (L->cxy[c] == CAND_NONE) { L->ccost[c] = PCAMV_COST_MAX; continue; }
         const int mx = CAND_X(c), my = CAND_Y(c);
-        int cost = prim_cost_luma_nolog(F, L, enc, ip, xoff, yoff, mx, my, satd);
+        const uint8_t *src = (flags & EV_SRC4) ? enc + (c & 3) * 384 : enc;
+        int cost = prim_cost_luma_nolog(F, L, src, ip, xoff, yoff, mx, my, satd);
         if (!(flags & EV_NOMV)) cost += F.cost_mv[mx - mvp0] + F.cost_mv[my - mvp1];
         if (flags & EV_CHROMA) {
             uint8_t tmp[8 * 8]; int w = pix_w_of(ip) / 2, h = pix_h_of(ip) / 2;
             for (int p = 0; p < 2; p++) {
                 emu_mc_chroma(F, tmp, 8, p, L->mb_x * 8 + (xoff >> 1), L->mb_y * 8 + (yoff >> 1), mx, my, w, h);
-                int cc = emu_cmp(w, h, enc + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
+                int cc = emu_cmp(w, h, src + 256 + (yoff >> 1) * 16 + p * 8 + (xoff >> 1), 16, tmp, 8, satd);
                 if (flags & EV_PROBE) L->ccost[64 * (1 + p) + c] = cc; else cost += cc;
             }
         }
@@ -262,6 +263,28 @@ static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
     }
     L->cbp_chroma = any_ac ? 2 : 0;
     prim_add_idct(F, L, keep, cmode[0], cmode[1]);
+}
+/* the four-at-once RCA re-encodes, scalar: one prediction / transform after the other */
+static inline void prim_predict_win16(const FrameDev &F, MBLocal *L, int j, int mvx, int mvy)
+{
+    uint8_t keep[24 * 16];
+    memcpy(keep, L->pred, sizeof(keep));
+    prim_predict_16x16(F, L, mvx, mvy, 1);
+    memcpy(L->pred4[j], L->pred, sizeof(keep));
+    memcpy(L->pred, keep, sizeof(keep));
+}
+static inline void prim_mb_transform4(const FrameDev &F, MBLocal *L)
+{
+    uint8_t in[4][24 * 16], keep[24 * 16];
+    memcpy(in, L->pred4, sizeof(in));          /* pred4 shares its storage with the coefficient scratch of the scalar transform */
+    memcpy(keep, L->pred, sizeof(keep));
+    for (int j = 0; j < 4; j++) {
+        memcpy(L->pred, in[j], sizeof(keep));
+        prim_mb_transform(F, L);
+        memcpy(in[j], L->pred, sizeof(keep));
+    }
+    memcpy(L->pred, keep, sizeof(keep));
+    memcpy(L->pred4, in, sizeof(in));
 }
 static inline int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
 {

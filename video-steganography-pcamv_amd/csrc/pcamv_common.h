@@ -94,9 +94,15 @@ struct MBLocal {
     uint8_t recb[24 * 16];         /* reconstruction in the same layout (fenc_buf_ih) */
     uint8_t recb0[24 * 16];        /* reconstruction of the macroblock as decided: shared by all its carriers' first RCA step */
     uint8_t pred[24 * 16];         /* prediction -> reconstruction, same layout */
-    int16_t coef[24][16];          /* per 4x4 block coefficients (luma 0..15, U 16..19, V 20..23) */
-    int16_t cdc[2][4];
-    int blk_nz[24], blk_score[24];
+    union {
+        struct {                       /* P_SKIP probe (search phase): per 4x4 block levels and their summaries */
+            int16_t coef[24][16];      /* luma 0..15, U 16..19, V 20..23 */
+            int16_t cdc[2][4];
+            int blk_nz[24], blk_score[24];
+            int red[64];               /* scratch for cross-lane work */
+        };
+        uint8_t pred4[4][24 * 16];     /* RCA phase: prediction -> reconstruction of four re-encodes made together */
+    };
     int16_t cmv[48][2];
     int8_t cref[48];
     int16_t pskip_mv[2];
@@ -106,7 +112,6 @@ struct MBLocal {
     int i_type, i_partition;
     uint8_t sub_part[4];
     int b_skip_mc, cbp_luma, cbp_chroma;
-    int red[64];                   /* scratch for cross-lane work */
     uint32_t cxy[64];              /* candidate list of the running evaluation: x | y << 16, quarter-pel; CAND_NONE = skip */
     int ccost[192];                /* cost of every listed candidate ([64..191]: per-plane chroma terms of the probe kernel) */
     int mvc16[9][2];               /* candidate MVs of the 16x16 search */
@@ -138,6 +143,7 @@ struct MBLocal {
 #define EV_NOMV 8      /* do not add the MV bit cost */
 #define EV_PROBE 16    /* chroma terms go to ccost[64 + c] (U) and ccost[128 + c] (V) instead of being added */
 #define EV_WIN 32      /* every candidate lies in the LDS reference window (L->win): no global loads */
+#define EV_SRC4 64     /* candidate c is measured against source block enc + (c & 3) * 384 (four re-encodes side by side; 16x16 only) */
 #define WIN_LW 24      /* luma window: bytes per row, rows, bytes per plane */
 #define WIN_LH 20
 #define WIN_LP (WIN_LW * WIN_LH)

@@ -540,6 +540,9 @@ extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double 
 extern "C" int pcamv_gpu_trace_mb(pcamv_ctx_t *c, int mb)
 {
     if (!c) return PCAMV_EINVAL;
+#ifndef PCAMV_TRACE
+    if (mb >= 0) return fail(c, PCAMV_EUNSUP, "tracing is compiled out: rebuild with -DPCAMV_TRACE");
+#endif
     HIPCHK(c, hipSetDevice(c->device));
     if (mb < 0) { c->F.trace = NULL; return 0; }
     if (!c->d_trace) HIPCHK(c, dalloc(&c->d_trace, (size_t)1 + 8 * 4000));

@@ -654,6 +654,31 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
     const int want_optimal = !(min_cost < me->cost_rec);
     min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
     int ii_best = -1;
+    if (win) {
+        /* 16x16 macroblock with its reference window in LDS: the four replacement MVs of a group are
+         * re-encoded together (their evaluations do not depend on each other, only the fold below does)
+         * and their 4 x 9 neighbourhood costs are one list, candidate c = 4 k + j for re-encode j,
+         * neighbour k; groups: ii = 0..3 always, 4..7 and 8..11 only when none of 0..3 qualified */
+        const int flags = (F.subme > 1 ? EV_SATD : 0) | (F.b_chroma_me ? EV_CHROMA : 0) | EV_WIN | EV_SRC4;
+        for (int grp = 0; grp < 3; grp++) {
+            for (int j = 0; j < 4; j++) prim_predict_win16(F, L, j, bmx + d_mv_x(4 * grp + j), bmy + d_mv_y(4 * grp + j));
+            prim_mb_transform4(F, L);
+            FOR_CAND(c, 36) {
+                int k = c >> 2, ii = 4 * grp + (c & 3);
+                L->cxy[c] = CAND_PACK(bmx + d_mv_x(ii) + d_nb_x(k), bmy + d_mv_y(ii) + d_nb_y(k));
+            }
+            eval_cands(F, L, me, L->pred4[0], 36, flags);
+            for (int j = 0; j < 4; j++) {
+                const int ii = 4 * grp + j;
+                int min1 = PCAMV_COST_MAX;
+                for (int k = 0; k < 9; k++) min1 = imin(min1, L->ccost[4 * k + j]);
+                cost = L->ccost[4 * 8 + j];
+                int is_opt = (min1 == cost);
+                if (is_opt == want_optimal && cost < min_cost) { min_cost = cost; *m_x = d_mv_x(ii); *m_y = d_mv_y(ii); ii_best = ii; }
+            }
+            if (grp == 0 && min_cost != PCAMV_COST_MAX) break;
+        }
+    } else
     for (int ii = 0; ii < 12; ii++) {
         int bx1 = bmx + d_mv_x(ii), by1 = bmy + d_mv_y(ii);
         me->mv[0] = bx1; me->mv[1] = by1;

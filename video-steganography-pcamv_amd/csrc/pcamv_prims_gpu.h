@@ -238,8 +238,9 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
         const int slot = lane >> lgn, blk = lane & (nblk - 1);
         const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
         uint32_t e[4], ec[8];
+        const uint8_t *encl = (flags & EV_SRC4) ? enc + (slot & 3) * 384 : enc;       /* the slot's source stays the same in every pass */
 #pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = lds4(enc + (py + k) * 16 + px);
+        for (int k = 0; k < 4; k++) e[k] = lds4(encl + (py + k) * 16 + px);
         if (satd) pk_cols(e, ec);
         const gp8 lb = (gp8)F.luma_base;
         const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size;
@@ -296,8 +297,9 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
         const int slot = lane >> (lgnb + 1), plane = (lane >> lgnb) & 1, blk = lane & (nb - 1);
         const int px = (xoff >> 1) + 4 * (blk & ((1 << lgcw) - 1)), py = (yoff >> 1) + 4 * (blk >> lgcw);
         uint32_t e[4], ec[8];
+        const uint8_t *encl = (flags & EV_SRC4) ? enc + (slot & 3) * 384 : enc;
 #pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = lds4(enc + 256 + (py + k) * 16 + plane * 8 + px);
+        for (int k = 0; k < 4; k++) e[k] = lds4(encl + 256 + (py + k) * 16 + plane * 8 + px);
         if (satd) pk_cols(e, ec);
         const gp8 cb = (gp8)F.chroma_base[0];
         const uint32_t cstride = (uint32_t)F.cstride;
@@ -336,12 +338,14 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
     EvalRes res;
     if (key == 0x7fffffff) { res.cost = PCAMV_COST_MAX; res.idx = -1; }
     else { res.cost = key >> 6; res.idx = key & 63; }
+#ifdef PCAMV_TRACE      /* diagnostics build only: log every candidate of one macroblock (pcamv_gpu_trace_mb) */
     if (F.trace && L->mb_xy == F.trace_mb && lane == 0)
         for (int c = 0; c < n; c++) {
             if (L->cxy[c] == CAND_NONE) continue;
             int k = F.trace[0];
             if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = ip; t[1] = xoff; t[2] = yoff; t[3] = CAND_X(c); t[4] = CAND_Y(c); t[5] = flags | ((enc == L->recb || enc == L->recb0) ? 32 : 0); t[6] = L->ccost[c]; t[7] = c; F.trace[0] = k + 1; }
         }
+#endif
     PCAMV_WAVE_SYNC();
     return res;
 }
@@ -462,22 +466,8 @@ __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L
  * (px,py) of the fenc/pred buffers (dct.c:122-170 sub4x4_dct, quant.c:33-109, 203-239).  d[] returns the
  * DEquantised levels (all zero when nothing survives), *rawdc the unquantised DC (chroma: its DC goes
  * through the 2x2 transform instead and d[0] is cleared before quantisation). */
-__device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+__device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
 {
-    int t[4][4];
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-        uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(L->pred + (py + y) * 16 + px);
-        int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
-        int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
-        int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
-        t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
-        d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
-    }
     *rawdc = d[0];
     if (!is_l) d[0] = 0;
     const int qp = is_l ? F.qp : F.chroma_qp;
@@ -521,6 +511,29 @@ __device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, in
         }
     }
     *nz_out = nz; *score_out = score;
+}
+/* forward transform of the lane's 4x4 block at (px,py): fenc minus the prediction buffer pred (dct.c:122-170) */
+__device__ __forceinline__ void residual_block_at(const FrameDev &F, MBLocal *L, const uint8_t *pred, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+{
+    int t[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(pred + (py + y) * 16 + px);
+        int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
+        int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
+        int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
+        t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+        d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
+    }
+    quant_score_dequant(F, is_l, d, nz_out, score_out, rawdc);
+}
+__device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+{
+    residual_block_at(F, L, L->pred, px, py, is_l, d, nz_out, score_out, rawdc);
 }
 /* one 4x4 block per lane into LDS (lanes 0..15 luma blocks in x264 block order, 16..19 U, 20..23 V):
  * the form the P_SKIP probe's wave-uniform checks read */
@@ -672,6 +685,80 @@ __device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
     L->cbp_chroma = ac_mask ? 2 : 0;
     PCAMV_WAVE_SYNC();
 }
+/* ---- four re-encodes of a 16x16 macroblock at once (RCA step, reference pixels in the LDS window) ---- */
+/* 16x16 prediction with one MV out of the window into pred4[j] */
+__device__ __forceinline__ void prim_predict_win16(const FrameDev &F, MBLocal *L, int j, int mvx, int mvy)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    uint8_t *dst = L->pred4[j];
+    { const int row = lane >> 2, c4 = lane & 3, dx = mvx & 3, dy = mvy & 3;
+      const int wb = (L->mb_y * 16 + row + PCAMV_PAD + (mvy >> 2) - L->win_y0) * WIN_LW + (L->mb_x * 16 + 4 * c4 + PCAMV_PAD + (mvx >> 2) - L->win_x0);
+      uint32_t v = wld4(L, wb + ((dx != 0) + 2 * (dy == 2)) * WIN_LP + (dy == 3 ? WIN_LW : 0));
+      if ((dx | dy) & 1) v = avg4(v, wld4(L, wb + (dy ? (2 + (dx == 2)) * WIN_LP : 0) + (dx == 3)));
+      sts4(dst + row * 16 + 4 * c4, v); }
+    { const int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3, dx = mvx & 7, dy = mvy & 7;
+      const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + row + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
+      const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+      const uint32_t a = wld4(L, b), bb = wld4(L, b + WIN_CW);
+      const uint32_t t = (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x05040100u), W, 32u, false) >> 6)
+                       | (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x06050201u), W, 32u, false) >> 6) << 8;
+      *(uint16_t *)(dst + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t; }
+    (void)F;
+    PCAMV_WAVE_SYNC();
+}
+/* transform stage of the four predictions in pred4 (same rules as prim_mb_transform): pass A, every lane
+ * one luma block (macroblock j = lane / 16: a DPP row each); pass B, lanes 0..31 one chroma block each
+ * (macroblock j = lane / 8, plane = quad) */
+__device__ __forceinline__ void prim_mb_transform4(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    {
+        const int j = lane >> 4, blk = lane & 15, px = 4 * blk_x_of(blk), py = 4 * blk_y_of(blk);
+        uint8_t *pr = L->pred4[j];
+        int16_t d[16]; int nz, score, rawdc;
+        residual_block_at(F, L, pr, px, py, true, d, &nz, &score, &rawdc);
+        const int sc = (nz && F.b_dct_decimate) ? score : 0;
+        int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8);
+        int any8 = nz | dpp_qp1(nz); any8 |= dpp_qp2(any8);
+        int row = q8 + dpp_hmir(q8); row += dpp_mir(row);
+        const bool keep = F.b_dct_decimate ? (q8 >= 4 && row >= 6) : any8 != 0;
+        if (keep && nz) idct4x4_add(pr + py * 16 + px, d);
+    }
+    if (lane < 32) {
+        const int j = lane >> 3, ch = (lane >> 2) & 1, ci = lane & 3, px = ch * 8 + (ci & 1) * 4, py = 16 + (ci >> 1) * 4;
+        uint8_t *pr = L->pred4[j];
+        int16_t d[16]; int nz, score, rawdc;
+        residual_block_at(F, L, pr, px, py, false, d, &nz, &score, &rawdc);
+        const int sc = (nz && F.b_dct_decimate) ? score : 0;
+        int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8);
+        int any8 = nz | dpp_qp1(nz); any8 |= dpp_qp2(any8);
+        const int cdc = quad_had2x2(rawdc, ci);
+        int dcq;
+        { const int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1;
+          dcq = cdc > 0 ? ((bias + cdc) * mf >> 16) : -((bias - cdc) * mf >> 16); }
+        int nzdc = dcq != 0; nzdc |= dpp_qp1(nzdc); nzdc |= dpp_qp2(nzdc);
+        int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        const int rdc = (int16_t)(quad_had2x2(dcq, ci) * dmf >> -qbits);
+        const int cmode = (q8 < 7 && F.b_dct_decimate) || !any8 ? (nzdc ? 1 : 0) : 2;
+        uint8_t *dst = pr + py * 16 + px;
+        if (cmode == 2) { if (nzdc) d[0] = (int16_t)rdc; idct4x4_add(dst, d); }
+        else if (cmode == 1) {
+            const int v = (rdc + 32) >> 6;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t p = lds4(dst + y * 16), o = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((p >> (8 * x)) & 255) + v, 0, 255) << (8 * x);
+                sts4(dst + y * 16, o);
+            }
+        }
+    }
+    PCAMV_WAVE_SYNC();
+}
+
 __device__ __forceinline__ int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
 {
     PCAMV_WAVE_SYNC();
