@@ -49,15 +49,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal on a one-GPU box only: PCAMV_BENCH_REHEARSE=1 puts every rank on GPU 0 and runs the (untimed)
+    # collectives over gloo, since RCCL refuses two ranks on one device; the driver's runs use RCCL, one GPU per rank
+    rehearse = os.environ.get("PCAMV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearse else dev          # where collective operands live
 
     W, H = args.width, args.height
     n_mb = (W // 16) * (H // 16)
@@ -100,7 +109,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -116,7 +125,7 @@ def main():
         from helpers import carrier_lsbs
         ext = pcamv_amd.stc_extract(carrier_lsbs(final), emb["m"])
         ber = float((ext != emb["message"]).mean())
-    summary = torch.tensor([emb["n"], emb["m"], emb["num_flip"]], device=dev, dtype=torch.int64)
+    summary = torch.tensor([emb["n"], emb["m"], emb["num_flip"]], device=cdev, dtype=torch.int64)
     if dist is not None:
         gathered = [torch.zeros_like(summary) for _ in range(world)]
         dist.all_gather(gathered, summary)      # per-GOP result summary to every rank over RCCL (not timed)

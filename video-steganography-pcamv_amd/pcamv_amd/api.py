@@ -280,9 +280,15 @@ class Encoder:
         self._chk(self.lib.pcamv_gpu_fetch_results(self.ctx, _p(mbs), C.byref(e) if want_embed else None), "fetch_results")
         return mbs, (self._embed_out(arr, e) if want_embed else None)
 
-    def kernel_time(self, kernel="k_search_diag", reset=True):
+    def kernel_time(self, kernel=None, reset=True):
+        """average launch time of the analysis kernel of the active schedule (k_analyse_flow, or k_search_diag under PCAMV_SCHED=diag)"""
         ms, n = C.c_double(), C.c_int()
-        self._chk(self.lib.pcamv_gpu_kernel_time(self.ctx, kernel.encode(), C.byref(ms), C.byref(n), int(reset)), "kernel_time")
+        names = [kernel] if kernel else ["k_analyse_flow", "k_search_diag"]
+        for nm in names:
+            rc = self.lib.pcamv_gpu_kernel_time(self.ctx, nm.encode(), C.byref(ms), C.byref(n), int(reset))
+            if rc == 0:
+                break
+        self._chk(rc, "kernel_time")
         return ms.value, n.value
 
 
