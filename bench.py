@@ -145,6 +145,16 @@ def main():
         with open(tfile) as fh:
             tj = json.load(fh)["k_analyse_flow_bytes_per_mb"]
         traffic = (tj["fetch_raw"] + tj["write"]) * mbs_per_launch
+    # what actually bounds the kernel (committed SQ counter summary of the same command): share of the SIMDs' issue
+    # slots in use = waves/SIMD x ACTIVE_INST_ANY / WAVE_CYCLES; the VALU alone = waves/SIMD x ACTIVE_INST_VALU / WAVE_CYCLES
+    issue = None
+    sfile = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary.json")
+    if dom == "k_analyse_flow" and os.path.exists(sfile):
+        with open(sfile) as fh:
+            sq = json.load(fh)["k_analyse_flow_totals"]
+        issue = {"waves_per_simd": 4, "issue_slots_used": 4 * sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                 "valu_busy": 4 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "wave_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                 "source": "profiles/r01_pmc_sq_summary.json"}
     out = {
         "metric": "1080p macroblocks/s (embed on)", "value": value, "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -158,7 +168,8 @@ def main():
         "hbm_algorithmic_GBps_whole_path": 5888.0 * value / 1e9,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic,
-                     "avg_launch_ms": avg_ms, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH},
+                     "avg_launch_ms": avg_ms, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH,
+                     "issue_bound": issue},
     }
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
