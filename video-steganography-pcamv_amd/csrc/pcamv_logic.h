@@ -220,15 +220,28 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
         if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx); bmy = CAND_Y(r.idx); }
         if (bmx == omx && bmy == omy) break;
     }
+    bdir = -1;
+    int first_done = 0;
     if (!b_refine_qpel) {
         /* COST_MV_SATD of the half-pel result; the conditional chroma terms of the reference only skip
          * work for candidates that cannot win, so the full cost decides identically */
         if (bmy > L->mv_max_spel[1]) bmy = L->mv_max_spel[1];
         L->cxy[0] = CAND_PACK(bmx, bmy);
-        bcost = eval_cands(F, L, me, L->fenc, 1, qflags).cost;
+        if (qpel_iters > 0) {
+            /* ... together with the first quarter-pel round around it (its four positions are known
+             * already): candidate 0 sets the cost to beat, 1..4 are folded in order */
+            const int omx = bmx, omy = bmy;
+            L->cxy[1] = CAND_PACK(omx, omy - 1); L->cxy[2] = CAND_PACK(omx, omy + 1);
+            L->cxy[3] = CAND_PACK(omx - 1, omy); L->cxy[4] = CAND_PACK(omx + 1, omy);
+            eval_cands(F, L, me, L->fenc, 5, qflags);
+            bcost = L->ccost[0];
+            for (int k = 1; k < 5; k++)
+                if (L->ccost[k] < bcost) { bcost = L->ccost[k]; bmx = CAND_X(k); bmy = CAND_Y(k); bdir = k - 1; }
+            first_done = (bmx == omx && bmy == omy) ? 2 : 1;       /* 2: no move, the round loop ends here */
+        } else
+            bcost = eval_cands(F, L, me, L->fenc, 1, qflags).cost;
     }
-    bdir = -1;
-    for (int i = qpel_iters; i > 0; i--) {
+    for (int i = qpel_iters - (first_done ? 1 : 0); i > 0 && first_done != 2; i--) {
         odir = bdir;
         int omx = bmx, omy = bmy;
         L->cxy[0] = CAND_PACK(omx, omy - 1); L->cxy[1] = CAND_PACK(omx, omy + 1);
@@ -299,6 +312,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     const int ip = me->i_pixel;
     int i_me_range = F.me_range;
     int bmx, bmy, bcost, bpred_mx = 0, bpred_my = 0, bpred_cost = PCAMV_COST_MAX, omx, omy, pmx, pmy;
+    int umh_ucost1 = 0, umh_diamonds_done = 0;
     const int mv_x_min = L->mv_min_fpel[0], mv_y_min = L->mv_min_fpel[1], mv_x_max = L->mv_max_fpel[0], mv_y_max = L->mv_max_fpel[1];
 
     bmx = clip3i(me->mvp[0], mv_x_min * 4, mv_x_max * 4);
@@ -319,7 +333,17 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
         bpred_cost = r.cost; bpred_mx = CAND_X(r.idx); bpred_my = CAND_Y(r.idx);
         bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
         FSET(0, bmx, bmy); FSET(1, 0, 0);
-        fpel_fold(F, L, me, bmx, bmy, bcost, 2);
+        if (F.me_method == PCAMV_ME_UMH) {
+            /* UMH goes on with the small diamonds around the predictor and around (0,0) (me.c:308-316),
+             * whose positions do not depend on the two tests above: one list, same order */
+            int n = 6;
+            FSET(2, pmx, pmy - 1); FSET(3, pmx, pmy + 1); FSET(4, pmx - 1, pmy); FSET(5, pmx + 1, pmy);
+            if (pmx | pmy) { FSET(6, 0, -1); FSET(7, 0, 1); FSET(8, -1, 0); FSET(9, 1, 0); n = 10; }
+            fpel_fold(F, L, me, bmx, bmy, bcost, n);
+            umh_ucost1 = imin(L->ccost[0], L->ccost[1]);
+            umh_diamonds_done = 1;
+        } else
+            fpel_fold(F, L, me, bmx, bmy, bcost, 2);
     } else {
         /* full-pel test: the predictor (its MV bits not charged), then the candidates, then (0,0).
          * Candidates equal to the running best are listed too: their cost cannot be smaller. */
@@ -368,9 +392,12 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
 #define SAD_THRESH(v) (bcost < ((v) >> size_shift_of(ip)))
-        ucost1 = bcost;
-        if (pmx | pmy) { TRY8(0, 0, pmx, pmy - 1, pmx, pmy + 1, pmx - 1, pmy, pmx + 1, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
-        else { TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
+        if (umh_diamonds_done) ucost1 = umh_ucost1;
+        else {
+            ucost1 = bcost;
+            if (pmx | pmy) { TRY8(0, 0, pmx, pmy - 1, pmx, pmy + 1, pmx - 1, pmy, pmx + 1, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
+            else { TRY4(pmx, pmy, 0, -1, 0, 1, -1, 0, 1, 0); }
+        }
         if (ip != PIX_4x4) {
             ucost2 = bcost;
             if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) { omx = bmx; omy = bmy; TRY4(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0); }
