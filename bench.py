@@ -103,6 +103,11 @@ def main():
         step(t)
     barrier()
     batch.kernel_time(reset=True)
+    prof = None
+    if os.environ.get("PCAMV_PROF_DUMP") == "1":      # diagnostics build of the library (-DPCAMV_PROF): wave cycles per phase
+        import ctypes
+        prof = (ctypes.c_ulonglong * 16)()
+        pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 1)
     t0 = time.perf_counter()
     for t in range(args.steps):
         step(args.warmup + t)
@@ -113,6 +118,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if prof is not None:
+        pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 0)
+        nmb = args.gops * n_mb * args.steps
+        names = ["pop+wait+acquire", "search", "publish", "reconstruct+RCA", "whole iteration"]
+        print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(5)}, file=sys.stderr)
     # dominant kernel: average duration of one launch, HIP events on its own stream
     dom = batch.dominant_kernel()
     avg_ms, n_launch = batch.kernel_time(reset=False)

@@ -74,6 +74,14 @@ static int bfail(pcamv_batch *b, int code, const char *fmt, ...)
 #define HIPCHKB(b, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bfail(b, PCAMV_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
+#ifdef PCAMV_PROF
+extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 extern "C" const char *pcamv_gpu_last_error(const pcamv_ctx_t *c) { return c ? c->err : "no context"; }
 
 template <class T> static hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }

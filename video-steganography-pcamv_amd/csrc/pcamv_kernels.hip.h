@@ -148,6 +148,14 @@ __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
  * residency or on workgroup->XCD placement: an entry index is only waited for after it was handed out,
  * entries are appended by waves that are running, and the dependency graph always has a ready node
  * until everything is done.  Spins are bounded; a timeout raises ctr[2] and every wave drains. */
+#ifdef PCAMV_PROF
+__device__ unsigned long long pcamv_prof[16];     /* diagnostics build: wave cycles per phase of k_analyse_flow */
+#define PROF_T() __builtin_readcyclecounter()
+#define PROF_ADD(i, t0) do { if (LANE() == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(PROF_T() - (t0))); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
+#endif
 struct FlowDev {
     unsigned *ctr;            /* [0..7] pop index of queue x, [8..15] append index of queue x, [16] error flag */
     unsigned *queue;          /* total entries, queue x at [qbase[x], qbase[x] + qcount[x]); 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
@@ -196,6 +204,7 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     int home = (int)(xcc & 7u) & (fl.nq - 1), tried = 0;
     for (;;) {
+        const unsigned long long t_pop = PROF_T();
         unsigned idx = 0;
         if (lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
         idx = flow_bcast(idx);
@@ -222,7 +231,11 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
         const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
         const FrameDev F = Fs[g];
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
+        PROF_ADD(0, t_pop);
+        const unsigned long long t_s = PROF_T();
         mbk_search(F, &L, &A, x, y);
+        PROF_ADD(1, t_s);
+        const unsigned long long t_p = PROF_T();
         /* publish: stores drained, L2 written back, then the counters / queue entries */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -235,7 +248,12 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
                 if (x == fl.mb_w - 1) flow_done_one(fl, q, base + xy + fl.mb_w, item + (unsigned)fl.mb_w);
             }
         }
+        PROF_ADD(2, t_p);
+        const unsigned long long t_r = PROF_T();
         if (fl.fused) mbk_rca_encode(F, &L, &A, xy);
+        PROF_ADD(3, t_r);
+        PROF_ADD(4, t_pop);
+        if (LANE() == 0) { PROF_ADD(5, PROF_T() - 1); }
     }
 }
 
