@@ -248,3 +248,46 @@ def test_1080p_batch_step_matches_oracle(pc):
     batch.close()
     for enc in encs:
         enc.close()
+
+
+SWEEP = [
+    # (W, H, me, me_range, subme, inter, qp, chroma_me, fast_pskip, dct_decimate, chroma_qp_offset, seed, static_cols)
+    (176, 144, "dia", 16, 1, 0x10, 12, 1, 1, 1, 0, 41, 48),      # qp < 24: rounding dequantiser
+    (176, 144, "hex", 16, 3, 0x10, 20, 1, 1, 1, 3, 42, 32),      # chroma QP offset
+    (176, 144, "umh", 24, 5, 0x10, 35, 0, 1, 1, 0, 43, 0),       # no chroma ME, wide UMH range
+    (176, 144, "umh", 8, 4, 0x30, 45, 1, 0, 1, -2, 44, 64),      # p4x4, no fast skip, high qp
+    (176, 144, "hex", 16, 5, 0x30, 30, 1, 1, 0, 0, 45, 16),      # no decimation
+    (176, 144, "esa", 8, 2, 0x10, 28, 1, 1, 1, 0, 46, 48),       # exhaustive, subme 2
+    (320, 240, "umh", 16, 5, 0x10, 24, 1, 1, 1, 0, 47, 96),      # borders of a wider picture, many skips
+    (176, 144, "esa", 16, 5, 0x30, 33, 1, 1, 1, 0, 48, 32),      # exhaustive with p4x4
+]
+
+
+@pytest.mark.parametrize("cfg", SWEEP, ids=[f"{c[2]}_r{c[3]}_s{c[4]}_i{c[5]:x}_qp{c[6]}" for c in SWEEP])
+def test_option_sweep_matches_oracle(pc, cfg):
+    """options and quantiser ranges the fixtures do not reach (the oracle is pinned to the reference on the
+    fixtures; here it carries that pin to more of the option space): two chained P frames, record +
+    reconstruction + RCA costs bit-exact"""
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H, me, me_range, subme, inter, qp, cme, fps, dec, cqo, seed, static = cfg
+    clip = make_clip(W, H, 3, seed=seed, static_cols=static)
+    mvr = pc.level_mv_range(W, H)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr, me_range)
+    p.b_chroma_me, p.b_fast_pskip, p.b_dct_decimate, p.i_chroma_qp_offset = cme, fps, dec, cqo
+    enc = pc.Encoder(p)
+    o = orc.Oracle(orc.make_params(W, H, me=me, me_range=me_range, subme=subme, mv_range=mvr, chroma_me=cme, fast_pskip=fps,
+                                   dct_decimate=dec, inter=inter, chroma_qp_offset=cqo))
+    ref, prev = clip[0], (None, None)
+    for t in (1, 2):
+        enc.set_ref(*ref, *prev); enc.upload_fenc(*clip[t])
+        o.set_ref(*ref, *prev); o.set_fenc(*clip[t])
+        mbs, rec = enc.analyse_pframe(qp, embed=1)
+        mbs_o, rec_o = o.analyse_pframe(qp, 1)
+        for f in mbs.dtype.names:
+            assert np.array_equal(mbs[f], mbs_o[f]), f"frame {t}: {f} at MBs {np.argwhere((mbs[f] != mbs_o[f]).reshape(len(mbs), -1).any(1)).ravel()[:6]}"
+        for a, b in zip(rec, rec_o):
+            assert np.array_equal(a, b), f"frame {t}: reconstruction"
+        prev = helpers.mv_field(mbs["mv"], W // 16, H // 16)
+        ref = rec
+    enc.close(); o.close()
