@@ -264,6 +264,60 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
     return 0;
 }
 
+/* Pass 2 of the fork's two-pass P frame (encoder.c:2380-2390 re-enters x264_slice_write with firstTime = 0):
+ * x264_macroblock_analyse forces type / partition / MVs from h->info.cache and swaps in mv_stego where
+ * h->info.filp says so (analyse.c:2574-2577, 2658-2679, 2870-3107), x264_macroblock_encode reconstructs,
+ * then the loop filter runs over the frame (x264_fdec_filter_row -> x264_frame_deblock_row).  Must follow
+ * refh_analyse_pframe on the same frame.  Dumps the final motion (incl. the skip MVs pass 2 predicts from
+ * the final neighbours), per-4x4 non-zero flags, the reconstruction before and after deblocking. */
+int refh_pass2_pframe(void *ctx, int qp, const int8_t *flips, int n_flips, refh_mb_t *out, uint8_t *nnz_out,
+                      uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, uint8_t *dbk_y, uint8_t *dbk_u, uint8_t *dbk_v)
+{
+    refh_t *c = ctx; x264_t *h = c->h;
+    if (n_flips < 0 || n_flips > 6336) return -1;
+    h->info.firstTime = 0;
+    h->info.i_mv_no = 0; h->info.num_mv_modify_real = 0;
+    memset(h->info.filp, 0, sizeof(h->info.filp));
+    memcpy(h->info.filp, flips, n_flips);
+    h->sh.i_type = SLICE_TYPE_P;
+    h->sh.i_disable_deblocking_filter_idc = 0; h->sh.i_alpha_c0_offset = 0; h->sh.i_beta_offset = 0;
+    x264_macroblock_slice_init(h);
+    x264_cabac_context_init(&h->cabac, h->sh.i_type, h->sh.i_qp, 0);
+    x264_cabac_encode_init(&h->cabac, h->out.p_bitstream, h->out.p_bitstream + h->out.i_bitstream);
+    h->mb.i_last_qp = qp; h->mb.i_last_dqp = 0;
+    for (int my = 0; my < c->mb_h; my++)
+        for (int mx = 0; mx < c->mb_w; mx++) {
+            int mb_xy = my * c->mb_w + mx;
+            x264_macroblock_cache_load(h, mx, my);
+            x264_macroblock_analyse(h);
+            x264_macroblock_encode(h);
+            refh_mb_t *o = &out[mb_xy];
+            memset(o, 0, sizeof(*o));
+            o->type = h->mb.i_type; o->partition = h->mb.i_partition; o->qp = h->mb.i_qp;
+            if (h->mb.i_type == P_8x8) memcpy(o->sub_partition, h->mb.i_sub_partition, 4);
+            else memset(o->sub_partition, D_L0_8x8, 4);
+            for (int i = 0; i < 16; i++) {
+                o->ref[i] = h->mb.cache.ref[0][x264_scan8[i]];
+                o->mv[i][0] = h->mb.cache.mv[0][x264_scan8[i]][0];
+                o->mv[i][1] = h->mb.cache.mv[0][x264_scan8[i]][1];
+                nnz_out[mb_xy * 16 + i] = h->mb.cache.non_zero_count[x264_scan8[i]];
+            }
+            o->pskip_mv[0] = h->mb.cache.pskip_mv[0]; o->pskip_mv[1] = h->mb.cache.pskip_mv[1];
+            x264_macroblock_cache_save(h);
+        }
+    x264_frame_t *f = h->fdec;
+    for (int pass = 0; pass < 2; pass++) {
+        uint8_t *py = pass ? dbk_y : rec_y, *pu = pass ? dbk_u : rec_u, *pv = pass ? dbk_v : rec_v;
+        if (pass) for (int my = 0; my < c->mb_h; my++) x264_frame_deblock_row(h, my);
+        for (int y = 0; y < c->height; y++) memcpy(py + (size_t)y * c->width, f->plane[0] + (size_t)y * f->i_stride[0], c->width);
+        for (int y = 0; y < c->height / 2; y++) {
+            memcpy(pu + (size_t)y * c->width / 2, f->plane[1] + (size_t)y * f->i_stride[1], c->width / 2);
+            memcpy(pv + (size_t)y * c->width / 2, f->plane[2] + (size_t)y * f->i_stride[2], c->width / 2);
+        }
+    }
+    return h->info.i_mv_no;
+}
+
 /* ---- primitive-level entry points (checkasm-style differential testing, tools/checkasm.c) ---- */
 int refh_sad(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.sad[i_pixel](a, sa, b, sb); }
 int refh_satd(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.satd[i_pixel](a, sa, b, sb); }

@@ -95,6 +95,20 @@ class Ref:
         lib().refh_analyse_pframe(self.ctx, self.qp if qp is None else qp, _p(mbs), _p(ry), _p(ru), _p(rv))
         return mbs, (ry, ru, rv)
 
+    def pass2_pframe(self, flips, qp=None):
+        """second pass + loop filter of the frame last analysed: final record, per-4x4 non-zero counts,
+        reconstruction before / after deblocking; returns also the number of carrier MVs pass 2 walked"""
+        n = self.mb_w * self.mb_h
+        flips = np.ascontiguousarray(flips, dtype=np.int8)
+        mbs = np.zeros(n, dtype=MB_DTYPE)
+        nnz = np.zeros((n, 16), np.uint8)
+        planes = [np.zeros((self.h >> s, self.w >> s), np.uint8) for s in (0, 1, 1, 0, 1, 1)]
+        lib().refh_pass2_pframe.restype = C.c_int
+        nmv = lib().refh_pass2_pframe(self.ctx, self.qp if qp is None else qp, _p(flips), len(flips), _p(mbs), _p(nnz), *[_p(a) for a in planes])
+        if nmv < 0:
+            raise RuntimeError("refh_pass2_pframe failed")
+        return mbs, nnz, tuple(planes[:3]), tuple(planes[3:]), nmv
+
     def me_search(self, qp, mb_x, mb_y, pixel, xoff, yoff, mvp, mvc):
         mvp = np.asarray(mvp, np.int16)
         mvc = np.ascontiguousarray(np.asarray(mvc, np.int16).reshape(-1, 2))
