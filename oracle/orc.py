@@ -153,6 +153,21 @@ class Oracle:
         lib().orc_final_mvs(self.ctx, C.byref(e), _p(out))
         return out
 
+    def pass2_pframe(self, qp, mbs, flips):
+        """final record, per-4x4 non-zero flags [n_mb, 16], reconstruction before / after the loop filter"""
+        n = len(mbs)
+        W, H = self.p.i_width, self.p.i_height
+        flips = np.ascontiguousarray(flips, np.uint8)
+        mbs = np.ascontiguousarray(mbs)
+        out = np.zeros(n, MB_DTYPE)
+        nnz = np.zeros((n, 16), np.uint8)
+        planes = [np.zeros((H >> s, W >> s), np.uint8) for s in (0, 1, 1, 0, 1, 1)]
+        lib().orc_pass2_pframe.restype = C.c_int
+        k = lib().orc_pass2_pframe(self.ctx, qp, _p(mbs), _p(flips), len(flips), _p(out), _p(nnz), *[_p(a) for a in planes])
+        if k < 0:
+            raise RuntimeError("orc_pass2_pframe: flip map shorter than the carriers of the record")
+        return out, nnz, tuple(planes[:3]), tuple(planes[3:]), k
+
     def me_search(self, qp, mb_x, mb_y, pixel, xoff, yoff, mvp, mvc):
         mvp = np.asarray(mvp, np.int16)
         mvc = np.ascontiguousarray(np.asarray(mvc, np.int16).reshape(-1, 2))

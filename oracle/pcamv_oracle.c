@@ -373,6 +373,7 @@ typedef struct {
     int b_chroma_me, subme, me_method;
     int b_skip_mc;
     int cbp_luma, cbp_chroma;
+    uint8_t nzq[16], nnz[16];                        /* luma 4x4: quantised to non-zero; still non-zero after decimation (h->mb.non_zero_count != 0) */
 } mbc_t;
 #define NB_LEFT 1
 #define NB_TOP 2
@@ -1118,6 +1119,7 @@ static void mb_encode(mbc_t *m)
             orc_mc_chroma(m->p_fdec[2], 32, m->fref[5], o->cstride, mvx, mvy, 8, 8);
         }
         m->cbp_luma = m->cbp_chroma = 0;
+        memset(m->nnz, 0, 16);
         return;
     }
     if (!m->b_skip_mc) mb_mc(m);
@@ -1130,7 +1132,9 @@ static void mb_encode(mbc_t *m)
         int dec8 = 0, cbp = 0;
         for (int i4 = 0; i4 < 4; i4++) {
             int idx = i8 * 4 + i4;
+            m->nzq[idx] = 0;
             if (quant4(dct[idx], o->quant_mf[0][qp], o->quant_bias[0][qp])) {
+                m->nzq[idx] = 1;
                 for (int k = 0; k < 16; k++) lvl[k] = dct[idx][zz4[k]];
                 dequant4(dct[idx], o->dequant_mf, qp);
                 if (b_decimate && dec8 < 6) dec8 += decimate_score(lvl, 16);
@@ -1151,6 +1155,7 @@ static void mb_encode(mbc_t *m)
                 if (m->cbp_luma & (1 << i8))
                     for (int i4 = 0; i4 < 4; i4++) { int idx = i8 * 4 + i4; add4x4_idct(m->p_fdec[0] + blk_x[idx] * 4 + blk_y[idx] * 4 * 32, dct[idx]); }
     }
+    for (int idx = 0; idx < 16; idx++) m->nnz[idx] = m->nzq[idx] && ((m->cbp_luma >> (idx >> 2)) & 1);   /* dropped 8x8s / macroblocks are zeroed (macroblock.c:716-751) */
     encode_chroma(m);
 }
 /* NOTE (macroblock.c:725-729): with decimation an 8x8 whose blocks quantise to non-zero but
@@ -1671,6 +1676,22 @@ int orc_embed_pframe(orc_t *o, const pcamv_mb_t *mbs, float emrate, const uint8_
 }
 
 /* pass-2 substitution, analyse.c:3001-3107: swap in mv_stego where flip[k] == 1 */
+/* the carrier slot that owns 4x4 block i (x264 block order) of a macroblock */
+static int carrier_of_block(const pcamv_mb_t *mb, int i)
+{
+    if (mb->i_type == PCAMV_P_8x8) {
+        int i8 = i >> 2, j = i & 3;
+        switch (mb->i_sub_partition[i8]) {
+        case PCAMV_D_L0_8x8: return 4 * i8;
+        case PCAMV_D_L0_4x8: return 4 * i8 + (j & 1);
+        case PCAMV_D_L0_8x4: return 4 * i8 + (j & 2);
+        default: return i;
+        }
+    }
+    if (mb->i_partition == PCAMV_D_8x16) return blk_x[i] < 2 ? 0 : 4;
+    if (mb->i_partition == PCAMV_D_16x8) return blk_y[i] < 2 ? 0 : 8;
+    return 0;
+}
 void orc_final_mvs(const orc_t *o, const pcamv_embed_t *e, pcamv_mb_t *mbs)
 {
     int k = 0;
@@ -1687,6 +1708,159 @@ void orc_final_mvs(const orc_t *o, const pcamv_embed_t *e, pcamv_mb_t *mbs)
 #include "stc_mats.inc"
 
 typedef struct { long hold; } lcg_t;
+/* ------------------------------------------------------------------------------------------
+ * Pass 2 and the loop filter.  Semantics: every carrier macroblock keeps its pass-1 type /
+ * partition and takes its MVs from the record, mv_stego where the flip map says so (analyse.c:2870-3107); a
+ * P_SKIP macroblock takes the skip prediction from its FINAL neighbours (what the reference's pass 2 leaves
+ * when its skip probe fires again, and what a decoder derives); x264_macroblock_encode; then
+ * x264_frame_deblock_row (common/frame.c:627-798) for inter macroblocks with the 4x4 transform.
+ * ---------------------------------------------------------------------------------------- */
+/* H.264 Tables 8-16 / 8-17 (alpha, beta, tc0 by indexA / indexB and bS), as common/frame.c:383-423 holds them */
+static const uint8_t dbk_alpha[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+                                      32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+static const uint8_t dbk_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+                                     9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+static const int8_t dbk_tc0[52][3] = {
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 1, 1}, {0, 1, 1}, {1, 1, 1},
+    {1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 2}, {1, 1, 2}, {1, 1, 2}, {1, 1, 2}, {1, 2, 3}, {1, 2, 3}, {2, 2, 3}, {2, 2, 4}, {2, 3, 4},
+    {2, 3, 4}, {3, 3, 5}, {3, 4, 6}, {3, 4, 6}, {4, 5, 7}, {4, 5, 8}, {4, 6, 9}, {5, 7, 10}, {6, 8, 11}, {6, 8, 13}, {7, 10, 14}, {8, 11, 16},
+    {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+
+/* one 4-sample group of an edge: pix -> first q sample, xs = step across the edge, ys = step along it */
+static void dbk_luma4(uint8_t *pix, int xs, int ys, int alpha, int beta, int tc0)
+{
+    for (int d = 0; d < 4; d++, pix += ys) {
+        int p2 = pix[-3 * xs], p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs], q2 = pix[2 * xs];
+        if (abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta) {
+            int tc = tc0, delta;
+            if (abs(p2 - p0) < beta) { pix[-2 * xs] = p1 + clip3(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0); tc++; }
+            if (abs(q2 - q0) < beta) { pix[xs] = q1 + clip3(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0); tc++; }
+            delta = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            pix[-xs] = clip_u8(p0 + delta); pix[0] = clip_u8(q0 - delta);
+        }
+    }
+}
+static void dbk_chroma2(uint8_t *pix, int xs, int ys, int alpha, int beta, int tc)
+{
+    for (int d = 0; d < 2; d++, pix += ys) {
+        int p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs];
+        if (abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta) {
+            int delta = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            pix[-xs] = clip_u8(p0 + delta); pix[0] = clip_u8(q0 - delta);
+        }
+    }
+}
+/* deblock_edge (frame.c:594-612): bS 1..3 -> tc0 column bS-1; bS 0 -> tc -1 (luma: skip; chroma: tc0+1 = 0 -> skip) */
+static void dbk_edge(uint8_t *pl, uint8_t *pu, uint8_t *pv, int xs, int ys, int cxs, int cys, const uint8_t bS[4], int qp, int qpc, int do_chroma)
+{
+    int alpha = dbk_alpha[qp], beta = dbk_beta[qp];
+    if (alpha && beta)
+        for (int i = 0; i < 4; i++)
+            if (bS[i]) dbk_luma4(pl + 4 * i * ys, xs, ys, alpha, beta, dbk_tc0[qp][bS[i] - 1]);
+    if (do_chroma) {
+        alpha = dbk_alpha[qpc]; beta = dbk_beta[qpc];
+        if (alpha && beta)
+            for (int i = 0; i < 4; i++)
+                if (bS[i]) {
+                    int tc = dbk_tc0[qpc][bS[i] - 1] + 1;
+                    dbk_chroma2(pu + 2 * i * cys, cxs, cys, alpha, beta, tc);
+                    dbk_chroma2(pv + 2 * i * cys, cxs, cys, alpha, beta, tc);
+                }
+    }
+}
+static void deblock_frame(orc_t *o, uint8_t *py, uint8_t *pu, uint8_t *pv, const uint8_t *nnz, int qp)
+{
+    const int W = o->p.i_width, CW = W / 2, s4 = 4 * o->mb_w, s8 = 2 * o->mb_w;
+    const int qpc = chroma_qp_tab[clip3(qp + o->p.i_chroma_qp_offset, 0, 51)];
+    const int qp_thresh = 15 - (o->p.i_chroma_qp_offset > 0 ? o->p.i_chroma_qp_offset : 0);
+    for (int my = 0; my < o->mb_h; my++)
+        for (int mx = 0; mx < o->mb_w; mx++) {
+            const int xy = my * o->mb_w + mx, type = o->mb_type[xy];
+            int edge_end = type == PCAMV_P_SKIP ? 1 : 4;
+            const int no_sub8x8 = type != PCAMV_P_8x8 || !(o->p.inter & PCAMV_ANALYSE_PSUB8x8);
+            if (qp <= qp_thresh) edge_end = 1;
+            uint8_t *y0 = py + (size_t)16 * my * W + 16 * mx, *u0 = pu + (size_t)8 * my * CW + 8 * mx, *v0 = pv + (size_t)8 * my * CW + 8 * mx;
+            for (int dir = 0; dir < 2; dir++)
+                for (int edge = (dir ? my == 0 : mx == 0) ? 1 : 0; edge < edge_end; edge++) {
+                    const int nxy = edge ? xy : (dir ? xy - o->mb_w : xy - 1);
+                    uint8_t bS[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < 4; i++) {
+                        int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
+                        int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
+                        /* non_zero_count is indexed in x264 block order: block of (x,y) */
+                        int bi = (x & 1) + 2 * (y & 1) + 4 * (x >> 1) + 8 * (y >> 1), bn = (xn & 1) + 2 * (yn & 1) + 4 * (xn >> 1) + 8 * (yn >> 1);
+                        if (nnz[xy * 16 + bi] || nnz[nxy * 16 + bn]) bS[i] = 2;
+                        else if (!(edge & no_sub8x8)) {
+                            if ((i & no_sub8x8) && bS[i - 1] != 2) bS[i] = bS[i - 1];
+                            else {
+                                /* 4x4 / 8x8 positions in the frame's motion field */
+                                int gx = 4 * mx + x, gy = 4 * my + y, gxn = dir == 0 ? gx - 1 : gx, gyn = dir == 0 ? gy : gy - 1;
+                                const int16_t *a = o->mv[gy * s4 + gx], *b = o->mv[gyn * s4 + gxn];
+                                if (o->ref8[(gy >> 1) * s8 + (gx >> 1)] != o->ref8[(gyn >> 1) * s8 + (gxn >> 1)] || abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4) bS[i] = 1;
+                            }
+                        }
+                    }
+                    if (!(bS[0] | bS[1] | bS[2] | bS[3])) continue;
+                    if (dir == 0) dbk_edge(y0 + 4 * edge, u0 + 2 * edge, v0 + 2 * edge, 1, W, 1, CW, bS, qp, qpc, !(edge & 1));
+                    else dbk_edge(y0 + (size_t)4 * edge * W, u0 + (size_t)2 * edge * CW, v0 + (size_t)2 * edge * CW, W, 1, CW, 1, bS, qp, qpc, !(edge & 1));
+                }
+        }
+}
+
+/* mbs: the pass-1 record (with mv_stego); flips: one flag per carrier in embedding order.  out (may alias
+ * nothing): final type / partition / MVs per macroblock; nnz: [n_mb][16] flags in x264 block order; rec /
+ * dbk: reconstruction before / after the loop filter.  Leaves the final motion field in the context. */
+int orc_pass2_pframe(orc_t *o, int qp, const pcamv_mb_t *mbs, const uint8_t *flips, int n_flips, pcamv_mb_t *out, uint8_t *nnz,
+                     uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, uint8_t *dbk_y, uint8_t *dbk_u, uint8_t *dbk_v)
+{
+    mbc_t *m = malloc(sizeof(*m));
+    int k = 0;
+    memset(o->mb_type, PCAMV_P_SKIP, o->n_mb);
+    for (int my = 0; my < o->mb_h; my++)
+        for (int mx = 0; mx < o->mb_w; mx++) {
+            const int xy = my * o->mb_w + mx;
+            const pcamv_mb_t *r = &mbs[xy];
+            pcamv_mb_t *f = &out[xy];
+            mb_load(o, m, mx, my, qp);
+            *f = *r;
+            m->i_type = r->i_type; m->i_partition = r->i_partition;
+            memcpy(m->sub_part, r->i_sub_partition, 4);
+            if (r->i_type == PCAMV_P_SKIP) {
+                m->i_partition = PCAMV_D_16x16;
+                for (int i = 0; i < 16; i++) { f->mv[i][0] = m->pskip_mv[0]; f->mv[i][1] = m->pskip_mv[1]; f->ref[i] = 0; }
+                f->pskip_mv[0] = m->pskip_mv[0]; f->pskip_mv[1] = m->pskip_mv[1];
+            } else {
+                int slots[16], n = carrier_slots(r, slots);
+                for (int j = 0; j < n; j++, k++) {
+                    if (k >= n_flips) { free(m); return -1; }
+                    if (!flips[k]) continue;
+                    /* the 4x4 blocks the carrier covers: same value in every slot the partition owns */
+                    int s0 = slots[j];
+                    for (int i = 0; i < 16; i++)
+                        if (carrier_of_block(r, i) == s0) { f->mv[i][0] = r->mv_stego[s0][0]; f->mv[i][1] = r->mv_stego[s0][1]; }
+                }
+            }
+            for (int i = 0; i < 16; i++) { m->cmv[scan8(i)][0] = f->mv[i][0]; m->cmv[scan8(i)][1] = f->mv[i][1]; m->cref[scan8(i)] = 0; }
+            mb_encode(m);
+            memcpy(nnz + (size_t)xy * 16, m->nnz, 16);
+            o->mb_type[xy] = m->i_type;
+            int s4 = 4 * o->mb_w, s8 = 2 * o->mb_w, b4 = 4 * (my * s4 + mx), b8 = 2 * (my * s8 + mx), W = o->p.i_width;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) { o->mv[b4 + y * s4 + x][0] = m->cmv[SCAN8_0 + x + 8 * y][0]; o->mv[b4 + y * s4 + x][1] = m->cmv[SCAN8_0 + x + 8 * y][1]; }
+            o->ref8[b8] = o->ref8[b8 + 1] = o->ref8[b8 + s8] = o->ref8[b8 + s8 + 1] = 0;
+            for (int y = 0; y < 16; y++) memcpy(o->frec[0] + (size_t)(my * 16 + y) * W + mx * 16, m->p_fdec[0] + y * 32, 16);
+            for (int c = 1; c < 3; c++)
+                for (int y = 0; y < 8; y++) memcpy(o->frec[c] + (size_t)(my * 8 + y) * (W / 2) + mx * 8, m->p_fdec[c] + y * 32, 8);
+        }
+    free(m);
+    size_t ysz = (size_t)o->p.i_width * o->p.i_height;
+    if (rec_y) { memcpy(rec_y, o->frec[0], ysz); memcpy(rec_u, o->frec[1], ysz / 4); memcpy(rec_v, o->frec[2], ysz / 4); }
+    deblock_frame(o, o->frec[0], o->frec[1], o->frec[2], nnz, qp);
+    if (dbk_y) { memcpy(dbk_y, o->frec[0], ysz); memcpy(dbk_u, o->frec[1], ysz / 4); memcpy(dbk_v, o->frec[2], ysz / 4); }
+    return k;
+}
+
 static int stc_myrand(lcg_t *s) { return (int)(((s->hold = s->hold * 214013L + 2531011L) >> 16) & 0x7fff); }   /* embed.h:134-139 */
 
 /* embed.h:276-306.  The reference's LCG state is a process-wide static (embed.h:134) that

@@ -34,6 +34,8 @@ int  orc_analyse_pframe(orc_t *o, int qp, int embed, pcamv_mb_t *out_mb,
                         uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v);
 int  orc_embed_pframe(orc_t *o, const pcamv_mb_t *mbs, float emrate, const uint8_t *message, int message_len,
                       pcamv_embed_t *out);
+int orc_pass2_pframe(orc_t *o, int qp, const pcamv_mb_t *mbs, const uint8_t *flips, int n_flips, pcamv_mb_t *out, uint8_t *nnz,
+                     uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, uint8_t *dbk_y, uint8_t *dbk_u, uint8_t *dbk_v);
 void orc_final_mvs(const orc_t *o, const pcamv_embed_t *e, pcamv_mb_t *mbs);
 
 int  orc_stc_embed(const uint8_t *cover, int n, const uint8_t *msg, int m, const float *rho,
