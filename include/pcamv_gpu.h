@@ -145,6 +145,16 @@ int pcamv_gpu_embed_pframe(pcamv_ctx_t *ctx, float emrate, const uint8_t *messag
 /* Apply the flip map to the record (pass-2 substitution, analyse.c:3001-3107): final MVs. */
 int pcamv_gpu_final_mvs(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb);
 
+/* Pass 2 of the frame last analysed (analyse.c:2870-3107 + x264_macroblock_encode, then the loop filter
+ * x264_frame_deblock_row, common/frame.c:627-798): final MVs = the record with mv_stego where flips[k] == 1
+ * (k = carrier index in embedding order; flips == NULL: the flip map the last embed_pframe left on the
+ * device), P_SKIP macroblocks take the skip prediction from their final neighbours; out_final (optional)
+ * receives the record with the final MVs, recon[3] the reconstruction before the loop filter, deblocked[3]
+ * after it.  The deblocked picture stays in the context's reconstruction planes (the next reference) and the
+ * final motion field is what PCAMV_PREV_FIELD_INTERNAL hands to the next frame.  One QP per frame (CQP). */
+int pcamv_gpu_pass2_pframe(pcamv_ctx_t *ctx, const uint8_t *flips, int n_flips, pcamv_mb_t *out_final,
+                           uint8_t *const recon[3], uint8_t *const deblocked[3]);
+
 /* Syndrome-trellis extraction (host side of the BER check): stego bits -> message bits. */
 int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int matrixheight, uint8_t *message);
 

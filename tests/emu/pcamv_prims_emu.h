@@ -232,6 +232,8 @@ static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
     if (F.b_dct_decimate && decimate_mb < 6) cbp = 0;
     for (int i8 = 0; i8 < 4; i8++) if (cbp & (1 << i8)) keep |= 0xFu << (4 * i8);
     L->cbp_luma = cbp;
+    L->nnz_mask = 0;
+    for (int idx = 0; idx < 16; idx++) if (((keep >> idx) & 1) && L->blk_nz[idx]) L->nnz_mask |= 1 << idx;
     /* chroma (encoder/macroblock.c:277-372) */
     int cmode[2], any_ac = 0;
     for (int ch = 0; ch < 2; ch++) {

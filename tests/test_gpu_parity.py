@@ -291,3 +291,57 @@ def test_option_sweep_matches_oracle(pc, cfg):
         prev = helpers.mv_field(mbs["mv"], W // 16, H // 16)
         ref = rec
     enc.close(); o.close()
+
+
+PASS2_GPU = [
+    # (W, H, me, subme, inter, qp, seed, static_cols, flip_rate)
+    (176, 144, "hex", 5, 0x00, 26, 5, 48, 0.3),
+    (352, 288, "umh", 4, 0x10, 22, 7, 0, 0.5),        # partitions, no skips
+    (352, 288, "hex", 5, 0x00, 38, 5, 0, 0.4),        # moving skips re-predicted from flipped neighbours
+    (320, 240, "hex", 5, 0x30, 18, 9, 96, 0.25),      # p4x4 carriers, fine quantiser (many bS = 2 edges)
+    (176, 144, "dia", 3, 0x10, 44, 8, 0, 0.35),       # coarse quantiser: strong filtering
+    (176, 144, "hex", 5, 0x10, 14, 11, 32, 0.3),      # qp <= 15: only macroblock edges are filtered
+]
+
+
+@pytest.mark.parametrize("cfg", PASS2_GPU, ids=[f"{c[0]}x{c[1]}_{c[2]}_i{c[4]:x}_qp{c[5]}" for c in PASS2_GPU])
+def test_pass2_and_loop_filter_match_oracle(pc, cfg):
+    """final MVs (flips applied, skips re-predicted), pass-2 reconstruction and the deblocked picture against the
+    oracle (itself pinned on the reference's second pass + x264_frame_deblock_row by the CPU suite); once with an
+    explicit flip map, once with the device flip map of the embedding stage"""
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H, me, subme, inter, qp, seed, static, rate = cfg
+    clip = make_clip(W, H, 2, seed=seed, static_cols=static)
+    mvr = pc.level_mv_range(W, H)
+    enc = pc.Encoder(_params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr))
+    o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter))
+    enc.set_ref(*clip[0]); enc.upload_fenc(*clip[1])
+    o.set_ref(*clip[0]); o.set_fenc(*clip[1])
+    mbs, _ = enc.analyse_pframe(qp, embed=1)
+    mbs_o, _ = o.analyse_pframe(qp, 1)
+    n = len(helpers.carrier_lsbs(mbs))
+    flips = (np.random.default_rng(seed).random(n) < rate).astype(np.uint8)
+    fin, rec, dbk = enc.pass2_pframe(flips)
+    fo, nnz_o, rec_o, dbk_o, k = o.pass2_pframe(qp, mbs_o, flips)
+    assert k == n
+    assert np.array_equal(fin["mv"], fo["mv"]), np.argwhere((fin["mv"] != fo["mv"]).reshape(len(fin), -1).any(1)).ravel()[:8]
+    for a, b, nm in zip(rec, rec_o, "yuv"):
+        assert np.array_equal(a, b), f"pass-2 reconstruction {nm}"
+    for a, b, nm in zip(dbk, dbk_o, "yuv"):
+        assert np.array_equal(a, b), f"deblocked {nm}: {np.argwhere(a != b)[:6].tolist()}"
+    assert qp < 20 or any((a != b).any() for a, b in zip(rec, dbk))        # (alpha = 0 below indexA 16: nothing to filter)
+    # the same through the embedding stage's own flip map
+    mbs, _ = enc.analyse_pframe(qp, embed=1)
+    emb = enc.embed_pframe(0.5)
+    fin2, _, dbk2 = enc.pass2_pframe()
+    o2 = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter))
+    o2.set_ref(*clip[0]); o2.set_fenc(*clip[1])
+    mbs_o2, _ = o2.analyse_pframe(qp, 1)
+    emb_o = o2.embed_pframe(mbs_o2, 0.5)
+    assert np.array_equal(emb["flip"], emb_o["flip"])
+    fo2, _, _, dbk_o2, _ = o2.pass2_pframe(qp, mbs_o2, (np.asarray(emb_o["flip"]) == 1).astype(np.uint8))
+    assert np.array_equal(fin2["mv"], fo2["mv"])
+    for a, b in zip(dbk2, dbk_o2):
+        assert np.array_equal(a, b)
+    enc.close(); o.close(); o2.close()

@@ -57,7 +57,7 @@ struct FrameDev {
     int16_t *mvp_aux;              /* [n_mb][16][2] search-time mvp of each carrier slot */
     const int16_t *cost_mv;        /* centre pointer of the lambda*bits table for this QP */
     /* parameters */
-    int qp, chroma_qp, lambda;
+    int qp, chroma_qp, lambda, chroma_qp_offset;
     int me_method, me_range, subme, mv_range, b_chroma_me, b_fast_pskip, b_dct_decimate, b_cabac;
     unsigned inter;
     int embed;
@@ -66,6 +66,10 @@ struct FrameDev {
     int dq_mf_c[3];
     int lambda2_chroma;            /* x264_lambda2_tab[chroma_qp] for the skip-probe SSD threshold */
     int *trace; int trace_mb;      /* diagnostics: log every block-cost evaluation of one MB (trace[0] = count) */
+    /* pass 2 (final MVs -> reconstruction -> loop filter) */
+    uint16_t *nnz;                 /* [n_mb] bit i: luma 4x4 block i (x264 block order) kept non-zero levels */
+    const int8_t *flip;            /* flip map of the embedding stage, one entry per carrier MV in embedding order */
+    const int *car_base;           /* [n_mb] index of the macroblock's first carrier in that order */
 };
 
 /* Small lookup tables live in registers as packed constants: a table in memory costs one global
@@ -112,6 +116,7 @@ struct MBLocal {
     int i_type, i_partition;
     uint8_t sub_part[4];
     int b_skip_mc, cbp_luma, cbp_chroma;
+    int nnz_mask;                  /* luma blocks with non-zero levels after the transform stage (bit = x264 block index) */
     uint32_t cxy[64];              /* candidate list of the running evaluation: x | y << 16, quarter-pel; CAND_NONE = skip */
     int ccost[192];                /* cost of every listed candidate ([64..191]: per-plane chroma terms of the probe kernel) */
     int mvc16[9][2];               /* candidate MVs of the 16x16 search */

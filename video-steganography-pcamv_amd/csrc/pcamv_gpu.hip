@@ -57,6 +57,7 @@ struct pcamv_ctx {
     float *d_rho; int8_t *d_flip; int *d_hdr, *d_rnd; unsigned *d_cols, *d_path; long long *d_lcg;
     int cap;
     int *d_trace;
+    uint16_t *d_nnz; int *d_car_base; int8_t *d_flip_user;     /* pass 2 */
     char err[256];
 };
 
@@ -226,6 +227,8 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     HIPCHK(c, dalloc(&c->d_rho, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_flip, (size_t)c->cap));
     HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 72)); HIPCHK(c, dalloc(&c->d_lcg, 1));
     HIPCHK(c, dalloc(&c->d_path, (size_t)c->cap * 32));
+    HIPCHK(c, dalloc(&c->d_nnz, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_car_base, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_flip_user, (size_t)c->cap));
+    HIPCHK(c, hipMemset(c->d_nnz, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_car_base, 0, (size_t)F.n_mb * 4));
     HIPCHK(c, hipMemset(c->d_hdr, 0, 8 * sizeof(int)));
     int rnd[40]; memset(rnd, 0, sizeof(rnd)); glibc_srand_state(rnd, 1);
     HIPCHK(c, hipMemcpy(c->d_rnd, rnd, sizeof(rnd), hipMemcpyHostToDevice));
@@ -237,10 +240,11 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
     F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
     F.rec_mb = c->d_rec_mb; F.mvp_aux = c->d_mvp_aux;
+    F.nnz = c->d_nnz; F.car_base = c->d_car_base; F.flip = c->d_flip;
     EmbedDev &E = c->E;
     E.mbs = c->d_rec_mb; E.n_mb = F.n_mb; E.cover = c->d_cover; E.stego = c->d_stego; E.message = c->d_message; E.rho = c->d_rho;
     E.flip = c->d_flip; E.hdr = c->d_hdr; E.blk_which = c->d_blk_which; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
-    E.lcg = c->d_lcg; E.cap = c->cap; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
+    E.lcg = c->d_lcg; E.cap = c->cap; E.car_base = c->d_car_base; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
     pcamv_ctx *one[1] = {c};
     int rc = pcamv_gpu_batch_create(one, 1, &c->self);
     if (rc) { pcamv_gpu_close(c); return rc; }
@@ -262,6 +266,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_blk_which); hipFree(c->d_user_msg); hipFree(c->d_rho);
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
     if (c->d_trace) hipFree(c->d_trace);
+    hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -371,6 +376,17 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         hipLaunchKernelGGL(k_embed_prepare, dim3(G), dim3(1024), 0, st, dE);
         hipLaunchKernelGGL(k_stc_forward, dim3(G), dim3(1024), 0, st, dE);
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
+    }
+    if (what & 8) {      /* pass 2: final MVs -> reconstruction, then the loop filter, both in anti-diagonal order */
+        for (int pass = 0; pass < 2; pass++)
+            for (int d = 0; d < b->n_diag; d++) {
+                int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+                int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+                int cnt = y_hi - y_lo + 1;
+                if (cnt <= 0) continue;
+                if (pass == 0) hipLaunchKernelGGL(k_pass2_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                else hipLaunchKernelGGL(k_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+            }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(b, PCAMV_EHIP, "kernel launch: %s", hipGetErrorString(e));
@@ -482,6 +498,85 @@ extern "C" int pcamv_gpu_embed_pframe(pcamv_ctx_t *c, float emrate, const uint8_
     int rc = ctx_launch(c, 4);
     if (rc) return rc;
     return fetch_embed(c, out);
+}
+
+/* Pass 2 of the frame last analysed: final MVs (the record with mv_stego where the flip map says so; the flip
+ * map of the last embed_pframe when flips == NULL), reconstruction, loop filter.  out_final / recon /
+ * deblocked may be NULL.  The deblocked picture stays on the device (the context's reconstruction planes) and
+ * the final motion field becomes the one PCAMV_PREV_FIELD_INTERNAL hands to the next frame. */
+extern "C" int pcamv_gpu_pass2_pframe(pcamv_ctx_t *c, const uint8_t *flips, int n_flips, pcamv_mb_t *out_final,
+                                      uint8_t *const recon[3], uint8_t *const deblocked[3])
+{
+    if (!c) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (flips) {
+        if (n_flips < 0 || n_flips > c->cap) return fail(c, PCAMV_EINVAL, "n_flips");
+        HIPCHK(c, hipMemset(c->d_flip_user, 0, (size_t)c->cap));
+        if (n_flips) HIPCHK(c, hipMemcpy(c->d_flip_user, flips, n_flips, hipMemcpyHostToDevice));
+        c->F.flip = c->d_flip_user;
+        /* carrier index of every macroblock from the record (the embedding stage may not have run) */
+        pcamv_mb_t *h = (pcamv_mb_t *)malloc((size_t)c->F.n_mb * sizeof(pcamv_mb_t));
+        int *base = (int *)malloc((size_t)c->F.n_mb * sizeof(int));
+        if (!h || !base) { free(h); free(base); return fail(c, PCAMV_ENOMEM, "pass2"); }
+        HIPCHK(c, hipMemcpy(h, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
+        int k = 0;
+        for (int xy = 0; xy < c->F.n_mb; xy++) {
+            base[xy] = k;
+            if (!h[xy].used) continue;
+            if (h[xy].i_type == PCAMV_P_8x8)
+                for (int i = 0; i < 4; i++) k += h[xy].i_sub_partition[i] == PCAMV_D_L0_8x8 ? 1 : h[xy].i_sub_partition[i] == PCAMV_D_L0_4x4 ? 4 : 2;
+            else k += h[xy].i_partition == PCAMV_D_16x16 ? 1 : 2;
+        }
+        hipError_t e = hipMemcpy(c->d_car_base, base, (size_t)c->F.n_mb * sizeof(int), hipMemcpyHostToDevice);
+        free(h); free(base);
+        if (e != hipSuccess) return fail(c, PCAMV_EHIP, "pass2: %s", hipGetErrorString(e));
+        if (k > n_flips) return fail(c, PCAMV_EINVAL, "flip map has %d entries, the record has %d carriers", n_flips, k);
+    } else c->F.flip = c->d_flip;
+    const size_t ysz = (size_t)c->F.w * c->F.h;
+    /* pass-2 reconstruction first (for callers that want it before the loop filter), then the filter */
+    pcamv_batch *b = c->self;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   /* pass 2 only */
+        const FrameDev *dF; const EmbedDev *dE; int slot;
+        int rc = batch_push_descs(b, c->stream, &dF, &dE, &slot);
+        if (rc) return fail(c, rc, "%s", b->err);
+        const FrameDev &F = c->F;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int d = 0; d < b->n_diag; d++) {
+                int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+                int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+                int cnt = y_hi - y_lo + 1;
+                if (cnt <= 0) continue;
+                if (pass == 0) hipLaunchKernelGGL(k_pass2_diag, dim3(cnt, 1), dim3(64), 0, c->stream, dF, d);
+                else hipLaunchKernelGGL(k_deblock_diag, dim3(cnt, 1), dim3(64), 0, c->stream, dF, d);
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            uint8_t *const *dst = pass == 0 ? recon : deblocked;
+            if (dst)
+                for (int i = 0; i < 3; i++)
+                    if (dst[i]) HIPCHK(c, hipMemcpy(dst[i], c->d_rec[i], i ? ysz / 4 : ysz, hipMemcpyDeviceToHost));
+        }
+        rc = batch_release_slot(b, slot, c->stream);
+        if (rc) return fail(c, rc, "%s", b->err);
+    }
+    if (out_final) {
+        HIPCHK(c, hipMemcpy(out_final, c->d_rec_mb, (size_t)c->F.n_mb * sizeof(pcamv_mb_t), hipMemcpyDeviceToHost));
+        int16_t *mv = (int16_t *)malloc((size_t)c->F.n_mb * 64);
+        if (!mv) return fail(c, PCAMV_ENOMEM, "pass2");
+        hipError_t e = hipMemcpy(mv, c->F.mv, (size_t)c->F.n_mb * 64, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(mv); return fail(c, PCAMV_EHIP, "pass2: %s", hipGetErrorString(e)); }
+        const int s4 = 4 * c->F.mb_w;
+        static const int bx[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3}, by[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
+        for (int xy = 0; xy < c->F.n_mb; xy++) {
+            const int mx = xy % c->F.mb_w, my = xy / c->F.mb_w;
+            for (int i = 0; i < 16; i++) {
+                const int16_t *s = mv + 2 * ((4 * my + by[i]) * s4 + 4 * mx + bx[i]);
+                out_final[xy].mv[i][0] = s[0]; out_final[xy].mv[i][1] = s[1]; out_final[xy].ref[i] = 0;
+            }
+        }
+        free(mv);
+    }
+    return 0;
 }
 
 /* one step of every context of the batch on resident inputs: plane production + analysis + embedding */

@@ -81,6 +81,6 @@ static inline void pcamv_frame_set_params(FrameDev *F, const pcamv_params_t *p)
     F->me_method = p->i_me_method; F->me_range = p->i_me_range; F->subme = p->i_subpel_refine; F->mv_range = p->i_mv_range;
     F->b_chroma_me = p->b_chroma_me && p->i_subpel_refine >= 5;     /* analyse.c:246-247 */
     F->b_fast_pskip = p->b_fast_pskip; F->b_dct_decimate = p->b_dct_decimate; F->b_cabac = p->b_cabac;
-    F->inter = p->inter; F->tscale = p->i_tscale;
+    F->inter = p->inter; F->tscale = p->i_tscale; F->chroma_qp_offset = p->i_chroma_qp_offset;
 }
 #endif

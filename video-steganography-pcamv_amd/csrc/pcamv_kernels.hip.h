@@ -137,6 +137,147 @@ __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
     mbk_encode(F, &L, &A, blockIdx.x);
 }
 
+/* ------------------------------------------------------------------ pass 2 + loop filter */
+__global__ void __launch_bounds__(64) k_pass2_diag(const FrameDev *__restrict__ Fs, int d)
+{
+    __shared__ MBLocal L;
+    const FrameDev F = Fs[blockIdx.y];
+    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    int y = y_lo + (int)blockIdx.x, x = d - 2 * y;
+    if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
+    mbk_pass2(F, &L, x, y);
+}
+
+/* H.264 Tables 8-16 / 8-17: alpha(indexA), beta(indexB), tc0(indexA, bS = 1..3) */
+__device__ static const uint8_t dbk_alpha_dev[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
+                                                     32, 36, 40, 45, 50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+__device__ static const uint8_t dbk_beta_dev[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8,
+                                                    9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+__device__ static const int8_t dbk_tc0_dev[52][3] = {
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 1, 1}, {0, 1, 1}, {1, 1, 1},
+    {1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 2}, {1, 1, 2}, {1, 1, 2}, {1, 1, 2}, {1, 2, 3}, {1, 2, 3}, {2, 2, 3}, {2, 2, 4}, {2, 3, 4},
+    {2, 3, 4}, {3, 3, 5}, {3, 4, 6}, {3, 4, 6}, {4, 5, 7}, {4, 5, 8}, {4, 6, 9}, {5, 7, 10}, {6, 8, 11}, {6, 8, 13}, {7, 10, 14}, {8, 11, 16},
+    {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+
+/* Loop filter of one macroblock (x264_frame_deblock_row, common/frame.c:627-798, inter macroblocks, 4x4
+ * transform, one QP): the macroblock and the 4 pixels left of / above it are staged in LDS, the 32
+ * boundary strengths are computed one per lane, then the four vertical and the four horizontal edges are
+ * filtered in order (one line per lane: 16 luma, 8 + 8 chroma on even edges) and the touched pixels go back.
+ * Needs (x-1,y), (x,y-1) and (x+1,y-1) filtered: same anti-diagonal order as the search. */
+__global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+{
+    __shared__ uint8_t sy[20][24];          /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
+    __shared__ uint8_t sc[2][12][16];       /* chroma rows / cols -4..7 */
+    __shared__ uint8_t sbs[2][4][4];
+    const FrameDev F = Fs[blockIdx.y];
+    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int my = y_lo + (int)blockIdx.x, mx = d - 2 * my;
+    if (my >= F.mb_h || mx < 0 || mx >= F.mb_w) return;
+    const int lane = LANE(), xy = my * F.mb_w + mx, W = F.w, CW = F.w >> 1;
+    const int gx = 16 * mx, gy = 16 * my, cgx = 8 * mx, cgy = 8 * my;
+    /* stage: 20 rows x 5 dwords of luma, 2 x 12 rows x 3 dwords of chroma (nothing outside the picture) */
+    for (int i = lane; i < 100; i += 64) {
+        const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
+        if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = *(const uint32_t *)(F.rec[0] + (size_t)(gy + r) * W + gx + c);
+    }
+    for (int i = lane; i < 72; i += 64) {
+        const int pl = i / 36, j = i % 36, r = j / 3 - 4, c = (j % 3) * 4 - 4;
+        if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = *(const uint32_t *)((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
+    }
+    /* boundary strengths */
+    const int type = F.mb_type[xy], qp = F.qp;
+    const int qp_thresh = 15 - (F.chroma_qp_offset > 0 ? F.chroma_qp_offset : 0);
+    const int edge_end = (type == PCAMV_P_SKIP || qp <= qp_thresh) ? 1 : 4;
+    const int no_sub8x8 = type != PCAMV_P_8x8 || !(F.inter & PCAMV_ANALYSE_PSUB8x8);
+    if (lane < 32) {
+        const int dir = lane >> 4, edge = (lane >> 2) & 3, i = lane & 3;
+        int bs = 0;
+        const bool on = edge < edge_end && !(edge == 0 && (dir ? my == 0 : mx == 0));
+        if (on) {
+            const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
+            const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
+            const int nxy = edge ? xy : (dir ? xy - F.mb_w : xy - 1);
+            const int bi = (x & 1) + 2 * (y & 1) + 4 * (x >> 1) + 8 * (y >> 1), bn = (xn & 1) + 2 * (yn & 1) + 4 * (xn >> 1) + 8 * (yn >> 1);
+            if (((F.nnz[xy] >> bi) & 1) || ((F.nnz[nxy] >> bn) & 1)) bs = 2;
+            else if (!(edge & no_sub8x8)) {
+                const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
+                const int fx = 4 * mx + x, fy = 4 * my + y, fxn = dir == 0 ? fx - 1 : fx, fyn = dir == 0 ? fy : fy - 1;
+                const int16_t *a = F.mv + 2 * (fy * s4 + fx), *b = F.mv + 2 * (fyn * s4 + fxn);
+                if (F.ref8[(fy >> 1) * s8 + (fx >> 1)] != F.ref8[(fyn >> 1) * s8 + (fxn >> 1)] || iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4) bs = 1;
+                bs |= 0x10;              /* marks "decided by the motion test" for the copy rule below */
+            }
+        }
+        sbs[dir][edge][i] = (uint8_t)bs;
+    }
+    __syncthreads();
+    {   /* frame.c:735-737: inside an 8x8 that cannot be split, the odd 4-pixel group repeats its left/upper
+         * neighbour's strength unless that one is 2 */
+        const int dir = (lane >> 4) & 1, edge = (lane >> 2) & 3, i = lane & 3;
+        int bs = sbs[dir][edge][i];
+        const int prev = i ? sbs[dir][edge][i - 1] & 0xf : 0;
+        __syncthreads();
+        if (lane < 32) {
+            if ((bs & 0x10) && (i & no_sub8x8) && prev != 2) bs = prev;
+            sbs[dir][edge][i] = (uint8_t)(bs & 0xf);
+        }
+    }
+    __syncthreads();
+    const int qpc = F.chroma_qp;
+    const int alpha = dbk_alpha_dev[qp], beta = dbk_beta_dev[qp], calpha = dbk_alpha_dev[qpc], cbeta = dbk_beta_dev[qpc];
+    for (int dir = 0; dir < 2; dir++)
+        for (int edge = 0; edge < 4; edge++) {
+            const uint32_t any = *(const uint32_t *)sbs[dir][edge];
+            if (any) {
+                if (lane < 16 && alpha && beta) {
+                    const int bs = sbs[dir][edge][lane >> 2];
+                    if (bs) {
+                        const int tc0 = dbk_tc0_dev[qp][bs - 1];
+                        uint8_t *q = dir == 0 ? &sy[lane + 4][4 * edge + 4] : &sy[4 * edge + 4][lane + 4];
+                        const int xs = dir == 0 ? 1 : 24;
+                        const int p2 = q[-3 * xs], p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs], q2 = q[2 * xs];
+                        if (iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta) {
+                            int tc = tc0;
+                            if (iabs(p2 - p0) < beta) { q[-2 * xs] = (uint8_t)(p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0)); tc++; }
+                            if (iabs(q2 - q0) < beta) { q[xs] = (uint8_t)(q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0)); tc++; }
+                            const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+                            q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
+                        }
+                    }
+                } else if (lane >= 16 && lane < 32 && !(edge & 1) && calpha && cbeta) {
+                    const int pl = (lane - 16) >> 3, l = (lane - 16) & 7, bs = sbs[dir][edge][l >> 1];
+                    if (bs) {
+                        const int tc = dbk_tc0_dev[qpc][bs - 1] + 1;
+                        uint8_t *q = dir == 0 ? &sc[pl][l + 4][2 * edge + 4] : &sc[pl][2 * edge + 4][l + 4];
+                        const int xs = dir == 0 ? 1 : 16;
+                        const int p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs];
+                        if (iabs(p0 - q0) < calpha && iabs(p1 - p0) < cbeta && iabs(q1 - q0) < cbeta) {
+                            const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+                            q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    /* write back: the macroblock, the 4 columns left of it (rows 0..15), the 4 rows above it (cols 0..15) */
+    { const int r = lane >> 2, c = (lane & 3) * 4;
+      *(uint32_t *)(F.rec[0] + (size_t)(gy + r) * W + gx + c) = *(const uint32_t *)&sy[r + 4][c + 4]; }
+    if (lane < 16 && mx > 0) *(uint32_t *)(F.rec[0] + (size_t)(gy + lane) * W + gx - 4) = *(const uint32_t *)&sy[lane + 4][0];
+    if (lane >= 16 && lane < 32 && my > 0) { const int r = (lane - 16) >> 2, c = ((lane - 16) & 3) * 4;
+      *(uint32_t *)(F.rec[0] + (size_t)(gy - 4 + r) * W + gx + c) = *(const uint32_t *)&sy[r][c + 4]; }
+    if (lane >= 32) {
+        const int pl = (lane - 32) >> 4, j = (lane - 32) & 15, r = j >> 1, c = (j & 1) * 4;
+        uint8_t *dst = pl ? F.rec[2] : F.rec[1];
+        *(uint32_t *)(dst + (size_t)(cgy + r) * CW + cgx + c) = *(const uint32_t *)&sc[pl][r + 4][c + 4];
+    }
+    __syncthreads();
+    if (lane < 16 && mx > 0) { const int pl = lane >> 3, r = lane & 7; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
+      *(uint32_t *)(dst + (size_t)(cgy + r) * CW + cgx - 4) = *(const uint32_t *)&sc[pl][r + 4][0]; }
+    if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
+      *(uint32_t *)(dst + (size_t)(cgy - 4 + r) * CW + cgx + c) = *(const uint32_t *)&sc[pl][r][c + 4]; }
+}
+
 /* ------------------------------------------------------------------ dataflow scheduling of the analysis
  * One persistent launch per frame step instead of one launch per anti-diagonal: macroblock (x,y) of a
  * GOP becomes ready when (x-1,y) and (x+1,y-1) [or (x,y-1) at the right edge] are done; ready
@@ -295,6 +436,7 @@ struct EmbedDev {
     float emrate;
     const uint8_t *user_message; int user_message_len;
     int cap;                  /* capacity of the per-carrier arrays */
+    int *car_base;            /* [n_mb] index of each macroblock's first carrier (pass 2 finds its flips there) */
 };
 
 __device__ __forceinline__ int dev_is01(int d) { return d == 0 || d == 1; }
@@ -357,6 +499,7 @@ __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restri
     for (int xy = lo; xy < hi; xy++) {
         const pcamv_mb_t *mb = &E.mbs[xy];
         int k = carrier_slots(mb->i_type, mb->i_partition, mb->i_sub_partition, mb->used, slots);
+        E.car_base[xy] = base;
         if (!k) continue;
         float rho[16];
         for (int i = 0; i < k; i++) {

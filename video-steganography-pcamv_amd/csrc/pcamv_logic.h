@@ -474,6 +474,7 @@ PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L, int win = 0)
             prim_predict_16x16(F, L, mvx, mvy, 1);
         }
         L->cbp_luma = L->cbp_chroma = 0;
+        L->nnz_mask = 0;
         return;
     }
     if (!L->b_skip_mc) prim_predict_mb(F, L, win);
@@ -747,6 +748,23 @@ PCAMV_DEV int carrier_slots(int i_type, int i_partition, const uint8_t *sub, int
         else if (i_partition == PCAMV_D_16x8) { slots[n++] = 0; slots[n++] = 8; }
     }
     return n;
+}
+
+/* the carrier slot that owns 4x4 block i (x264 block order) */
+PCAMV_DEV int carrier_of_block(int i_type, int i_partition, const uint8_t *sub, int i)
+{
+    if (i_type == PCAMV_P_8x8) {
+        const int i8 = i >> 2, j = i & 3;
+        switch (sub[i8]) {
+        case PCAMV_D_L0_8x8: return 4 * i8;
+        case PCAMV_D_L0_4x8: return 4 * i8 + (j & 1);
+        case PCAMV_D_L0_8x4: return 4 * i8 + (j & 2);
+        default: return i;
+        }
+    }
+    if (i_partition == PCAMV_D_8x16) return blk_x_of(i) < 2 ? 0 : 4;
+    if (i_partition == PCAMV_D_16x8) return blk_y_of(i) < 2 ? 0 : 8;
+    return 0;
 }
 
 /* ---------------------------------------------------------------- phase A: search + decision */

@@ -129,6 +129,52 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
     }
 }
 
+/* pass 2 of one macroblock (analyse.c:2870-3107 + x264_macroblock_encode, semantics of DESIGN.md 5b): the
+ * pass-1 type / partition, the record's MVs with mv_stego where the flip map says so, for a P_SKIP
+ * macroblock the skip prediction from the FINAL neighbours; reconstruction; final motion + non-zero flags
+ * for the loop filter and for the next frame's temporal candidates.  Same left / top / top-right
+ * dependency as the search. */
+PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
+{
+    mb_load(F, L, mb_x, mb_y);
+    const int xy = L->mb_xy;
+    const pcamv_mb_t *r = &F.rec_mb[xy];
+    L->i_type = r->i_type; L->i_partition = r->i_partition;
+    for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
+    cache_ref_set(L, 0, 0, 4, 4, 0);
+    if (L->i_type == PCAMV_P_SKIP) {
+        L->i_partition = PCAMV_D_16x16;
+        cache_mv_set(L, 0, 0, 4, 4, L->pskip_mv[0], L->pskip_mv[1]);
+    } else {
+        int *slots = L->slots;
+        const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, r->used, slots);
+        const int base = F.car_base ? F.car_base[xy] : 0;
+        PCAMV_WAVE_SYNC();
+        FOR_CAND(i, 16) {
+            const int s = carrier_of_block(L->i_type, L->i_partition, L->sub_part, i);
+            int flipped = 0;
+            for (int j = 0; j < n; j++) if (slots[j] == s) flipped = F.flip ? F.flip[base + j] == 1 : 0;
+            L->cmv[scan8_of(i)][0] = flipped ? r->mv_stego[s][0] : r->mv[i][0];
+            L->cmv[scan8_of(i)][1] = flipped ? r->mv_stego[s][1] : r->mv[i][1];
+        }
+        PCAMV_WAVE_SYNC();
+    }
+    mb_encode(F, L);
+    prim_store_rec(F, L);
+    const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+    PCAMV_WAVE_SYNC();
+    FOR_CAND(i, 16) {
+        int x = i & 3, y = i >> 2;
+        F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
+        F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
+    }
+    if (PCAMV_LANE0) {
+        F.mb_type[xy] = (int8_t)L->i_type;
+        F.ref8[b8] = F.ref8[b8 + 1] = F.ref8[b8 + s8] = F.ref8[b8 + s8 + 1] = 0;
+        F.nnz[xy] = (uint16_t)L->nnz_mask;
+    }
+}
+
 PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
 {
     analysis_from_record(F, L, a, xy, L->slots);

@@ -681,6 +681,7 @@ __device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
             }
         }
     }
+    L->nnz_mask = (int)(__ballot(is_l && keep && nz) & 0xffffu);
     L->cbp_luma = (int)((keep_mask & 1) | ((keep_mask >> 3) & 2) | ((keep_mask >> 6) & 4) | ((keep_mask >> 9) & 8));
     L->cbp_chroma = ac_mask ? 2 : 0;
     PCAMV_WAVE_SYNC();

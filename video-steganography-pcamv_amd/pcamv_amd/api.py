@@ -247,6 +247,19 @@ class Encoder:
         self._chk(self.lib.pcamv_gpu_final_mvs(self.ctx, _p(out)), "final_mvs")
         return out
 
+    def pass2_pframe(self, flips=None):
+        """pass 2 + loop filter of the frame last analysed: (final record, reconstruction, deblocked picture);
+        flips = None uses the flip map of the last embed_pframe"""
+        out = np.zeros(self.n_mb, MB_DTYPE)
+        W, H = self.p.i_width, self.p.i_height
+        planes = [np.zeros((H >> s, W >> s), np.uint8) for s in (0, 1, 1, 0, 1, 1)]
+        rec = (C.c_void_p * 3)(*[a.ctypes.data for a in planes[:3]])
+        dbk = (C.c_void_p * 3)(*[a.ctypes.data for a in planes[3:]])
+        if flips is not None:
+            flips = np.ascontiguousarray(flips, np.uint8)
+        self._chk(self.lib.pcamv_gpu_pass2_pframe(self.ctx, _p(flips), 0 if flips is None else len(flips), _p(out), rec, dbk), "pass2_pframe")
+        return out, tuple(planes[:3]), tuple(planes[3:])
+
     def block_costs(self, qp, requests):
         req = np.ascontiguousarray(requests, np.int32).reshape(-1, 8)
         out = np.zeros((len(req), 3), np.int32)
