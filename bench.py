@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--subme", type=int, default=5)
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--emrate", type=float, default=0.5)
+    ap.add_argument("--closed-loop", action="store_true", help="also run pass 2 + the loop filter and use the deblocked reconstruction as the next reference")
     ap.add_argument("--cpu-frames", type=int, default=6, help="P frames timed for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -80,6 +81,10 @@ def main():
     dframes = [[torch.from_numpy(pl).to(dev) for pl in fr] for fr in clip]
     encs = [pcamv_amd.Encoder(p, device=local) for _ in range(args.gops)]
     batch = pcamv_amd.Batch(encs)          # all GOPs advance together: one launch per dependency step
+    if args.closed_loop:
+        batch.set_closed_loop(True)
+    recon = [enc.recon_device() for enc in encs]
+    started = [False]
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
 
@@ -89,9 +94,13 @@ def main():
             b = dframes[(t + g + 1) % nfr]
             # reference = previous source frame (open loop: the deblocked pass-2 reconstruction that
             # closes the loop in the encoder is produced by the host), chained MV field
-            enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            if args.closed_loop and started[0]:     # reference = this GOP's own deblocked reconstruction of the previous step
+                enc.set_ref_device(recon[g][0], recon[g][1], recon[g][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            else:
+                enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
             enc.set_fenc_device(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
         batch.step(args.qp, args.emrate, stream.cuda_stream)
+        started[0] = True
 
     def barrier():
         torch.cuda.synchronize()
@@ -170,7 +179,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{W}x{H} synthetic I420, --me {args.me} --subme {args.subme} --qp {args.qp} "
-                               f"--emrate {args.emrate}, {args.gops} closed GOPs in flight per GPU, open-loop reference",
+                               f"--emrate {args.emrate}, {args.gops} closed GOPs in flight per GPU, " + ("closed loop (pass 2 + loop filter on the GPU)" if args.closed_loop else "open-loop reference"),
                    "mb_per_frame": n_mb, "frames_per_step_per_gpu": args.gops,
                    "note": "BASELINE config 3 asks --subme 7; subme>=6 needs CABAC-size RDO (SURVEY 8f rank 3), not on the GPU path yet"},
         "extracted_payload_BER": ber,

@@ -186,6 +186,11 @@ void pcamv_gpu_batch_destroy(pcamv_batch_t *batch);
 int  pcamv_gpu_batch_step(pcamv_batch_t *batch, int qp, float emrate, void *stream);
 int  pcamv_gpu_batch_kernel_time(pcamv_batch_t *batch, const char *kernel, double *avg_ms, int *launches, int reset);
 const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *batch);
+/* Closed loop on the device: with on != 0 every batch step ends with pass 2 + the loop filter (embedding must be
+ * on: the flip map comes from it), leaving each context's deblocked reconstruction in its device planes
+ * (pcamv_gpu_recon_device) -- hand those to set_ref_device as the next frame's reference. */
+int  pcamv_gpu_batch_set_closed_loop(pcamv_batch_t *batch, int on);
+int  pcamv_gpu_recon_device(pcamv_ctx_t *ctx, void *planes[3]);
 /* name of the analysis kernel the batch's schedule launches ("k_analyse_flow" or "k_search_diag") */
 const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *batch);
 

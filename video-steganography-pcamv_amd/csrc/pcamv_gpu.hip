@@ -32,7 +32,7 @@ struct pcamv_batch {
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
-    int sched_flow, flow_waves;
+    int sched_flow, flow_waves, closed_loop;
     unsigned *d_flow;
     FlowDev fl;
     char err[256];
@@ -180,6 +180,13 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     return 0;
 }
 extern "C" const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *b) { return b ? b->err : "no batch"; }
+extern "C" int pcamv_gpu_batch_set_closed_loop(pcamv_batch_t *b, int on) { if (!b) return PCAMV_EINVAL; b->closed_loop = on != 0; return 0; }
+extern "C" int pcamv_gpu_recon_device(pcamv_ctx_t *c, void *planes[3])
+{
+    if (!c || !planes) return PCAMV_EINVAL;
+    for (int i = 0; i < 3; i++) planes[i] = c->d_rec[i];
+    return 0;
+}
 extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) { return b && b->sched_flow ? "k_analyse_flow" : "k_search_diag"; }
 
 /* ------------------------------------------------------------------ contexts */
@@ -592,7 +599,7 @@ extern "C" int pcamv_gpu_batch_step(pcamv_batch_t *b, int qp, float emrate, void
         c->F.embed = emrate > 0; c->E.emrate = emrate; c->E.user_message = NULL; c->E.user_message_len = 0;
     }
     hipStream_t st = stream ? (hipStream_t)stream : b->ctx[0]->stream;
-    return batch_launch(b, emrate > 0 ? 7 : 3, st, 1);
+    return batch_launch(b, (emrate > 0 ? 7 : 3) | (b->closed_loop ? 8 : 0), st, 1);
 }
 extern "C" int pcamv_gpu_step_device(pcamv_ctx_t *c, int qp, float emrate, void *stream)
 {

@@ -281,6 +281,12 @@ class Encoder:
         self._chk(self.lib.pcamv_gpu_set_ref_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v),
                                                     C.c_void_p(prev_mv or None), C.c_void_p(prev_ref or None)), "set_ref_device")
 
+    def recon_device(self):
+        """device pointers of the context's reconstruction planes (after a closed-loop step: the deblocked picture)"""
+        out = (C.c_void_p * 3)()
+        self._chk(self.lib.pcamv_gpu_recon_device(self.ctx, out), "recon_device")
+        return [int(out[i]) for i in range(3)]
+
     def set_fenc_device(self, y, u, v):
         self._chk(self.lib.pcamv_gpu_set_fenc_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v)), "set_fenc_device")
 
@@ -326,6 +332,10 @@ class Batch:
         rc = self.lib.pcamv_gpu_batch_step(self.b, qp, C.c_float(emrate), C.c_void_p(stream or None))
         if rc:
             raise PcamvError(f"batch_step failed ({rc}): {self.lib.pcamv_gpu_batch_last_error(self.b).decode()}")
+
+    def set_closed_loop(self, on=True):
+        if self.lib.pcamv_gpu_batch_set_closed_loop(self.b, int(on)):
+            raise PcamvError("batch_set_closed_loop failed")
 
     def dominant_kernel(self):
         self.lib.pcamv_gpu_batch_dominant_kernel.restype = C.c_char_p
