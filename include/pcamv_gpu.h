@@ -191,6 +191,8 @@ const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *batch);
  * (pcamv_gpu_recon_device) -- hand those to set_ref_device as the next frame's reference. */
 int  pcamv_gpu_batch_set_closed_loop(pcamv_batch_t *batch, int on);
 int  pcamv_gpu_recon_device(pcamv_ctx_t *ctx, void *planes[3]);
+/* host copy of those planes (tightly packed w*h, w/2*h/2 x2) after synchronising */
+int  pcamv_gpu_fetch_recon(pcamv_ctx_t *ctx, uint8_t *const planes[3]);
 /* name of the analysis kernel the batch's schedule launches ("k_analyse_flow" or "k_search_diag") */
 const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *batch);
 

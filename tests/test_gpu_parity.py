@@ -345,3 +345,53 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     for a, b in zip(dbk2, dbk_o2):
         assert np.array_equal(a, b)
     enc.close(); o.close(); o2.close()
+
+
+def test_closed_loop_batch_step_matches_oracle(pc):
+    """two GOPs advanced together through two closed-loop steps (dataflow analysis, embedding, then pass 2 + loop
+    filter in anti-diagonal launches; the second step's reference is the first step's deblocked picture
+    and final motion field, both taken from the device): records, embedding and deblocked pictures vs the oracle"""
+    import torch
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H, qp = 352, 288, 30
+    clips = [make_clip(W, H, 3, seed=61 + g, static_cols=64 * g) for g in range(2)]
+    dev = torch.device("cuda", 0)
+    d = [[[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip] for clip in clips]
+    mvr = pc.level_mv_range(W, H)
+    p = _params(pc, W, H, pc.ME_NAMES["hex"], 5, 0x10, mvr)
+    encs = [pc.Encoder(p) for _ in range(2)]
+    batch = pc.Batch(encs)
+    batch.set_closed_loop(True)
+    oracles = [orc.Oracle(orc.make_params(W, H, me="hex", subme=5, mv_range=mvr)) for _ in range(2)]
+    refs = [clips[g][0] for g in range(2)]
+    prevs = [(None, None), (None, None)]
+    for t in (1, 2):
+        for g, enc in enumerate(encs):
+            if t == 1:      # (the internal field of a fresh context holds no motion: same as no previous frame)
+                enc.set_ref_device(d[g][0][0].data_ptr(), d[g][0][1].data_ptr(), d[g][0][2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            else:
+                r = enc.recon_device()
+                enc.set_ref_device(r[0], r[1], r[2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            enc.set_fenc_device(d[g][t][0].data_ptr(), d[g][t][1].data_ptr(), d[g][t][2].data_ptr())
+        batch.step(qp, 0.5, 0)
+        for g, enc in enumerate(encs):
+            o = oracles[g]
+            mbs, emb = enc.fetch_results(want_embed=True)
+            o.set_ref(*refs[g], *prevs[g]); o.set_fenc(*clips[g][t])
+            mbs_o, _ = o.analyse_pframe(qp, 1)
+            for f in mbs.dtype.names:
+                assert np.array_equal(mbs[f], mbs_o[f]), f"step {t} GOP {g}: {f}"
+            emb_o = o.embed_pframe(mbs_o, 0.5)
+            assert np.array_equal(emb["flip"], emb_o["flip"]), f"step {t} GOP {g}: flips"
+            fo, _, _, dbk_o, _ = o.pass2_pframe(qp, mbs_o, (np.asarray(emb_o["flip"]) == 1).astype(np.uint8))
+            dbk = enc.fetch_recon()
+            for a, b, nm in zip(dbk, dbk_o, "yuv"):
+                assert np.array_equal(a, b), f"step {t} GOP {g}: deblocked {nm}"
+            refs[g] = dbk_o
+            prevs[g] = helpers.mv_field(fo["mv"], W // 16, H // 16)
+    batch.close()
+    for enc in encs:
+        enc.close()
+    for o in oracles:
+        o.close()

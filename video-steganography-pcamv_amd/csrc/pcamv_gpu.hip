@@ -181,6 +181,18 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
 }
 extern "C" const char *pcamv_gpu_batch_last_error(const pcamv_batch_t *b) { return b ? b->err : "no batch"; }
 extern "C" int pcamv_gpu_batch_set_closed_loop(pcamv_batch_t *b, int on) { if (!b) return PCAMV_EINVAL; b->closed_loop = on != 0; return 0; }
+static int flow_check(pcamv_batch *b);
+extern "C" int pcamv_gpu_fetch_recon(pcamv_ctx_t *c, uint8_t *const planes[3])
+{
+    if (!c || !planes) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->last) { int rc = flow_check(c->last); if (rc) return fail(c, rc, "%s", c->last->err); }
+    const size_t ysz = (size_t)c->F.w * c->F.h;
+    for (int i = 0; i < 3; i++)
+        if (planes[i]) HIPCHK(c, hipMemcpy(planes[i], c->d_rec[i], i ? ysz / 4 : ysz, hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int pcamv_gpu_recon_device(pcamv_ctx_t *c, void *planes[3])
 {
     if (!c || !planes) return PCAMV_EINVAL;
@@ -384,16 +396,17 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         hipLaunchKernelGGL(k_stc_forward, dim3(G), dim3(1024), 0, st, dE);
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
     }
-    if (what & 8) {      /* pass 2: final MVs -> reconstruction, then the loop filter, both in anti-diagonal order */
-        for (int pass = 0; pass < 2; pass++)
-            for (int d = 0; d < b->n_diag; d++) {
-                int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-                int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
-                int cnt = y_hi - y_lo + 1;
-                if (cnt <= 0) continue;
-                if (pass == 0) hipLaunchKernelGGL(k_pass2_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
-                else hipLaunchKernelGGL(k_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
-            }
+    if (what & 8) {      /* pass 2: final MVs -> reconstruction -> loop filter, same dependency as the search */
+        /* per anti-diagonal launches: these tasks are too short for the dataflow queue's per-macroblock release */
+            for (int pass = 0; pass < 2; pass++)
+                for (int d = 0; d < b->n_diag; d++) {
+                    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+                    int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+                    int cnt = y_hi - y_lo + 1;
+                    if (cnt <= 0) continue;
+                    if (pass == 0) hipLaunchKernelGGL(k_pass2_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                    else hipLaunchKernelGGL(k_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(b, PCAMV_EHIP, "kernel launch: %s", hipGetErrorString(e));

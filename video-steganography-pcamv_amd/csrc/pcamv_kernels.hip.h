@@ -165,15 +165,12 @@ __device__ static const int8_t dbk_tc0_dev[52][3] = {
  * boundary strengths are computed one per lane, then the four vertical and the four horizontal edges are
  * filtered in order (one line per lane: 16 luma, 8 + 8 chroma on even edges) and the touched pixels go back.
  * Needs (x-1,y), (x,y-1) and (x+1,y-1) filtered: same anti-diagonal order as the search. */
-__global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+struct DeblockLDS { uint8_t sy[20][24]; uint8_t sc[2][12][16]; uint8_t sbs[2][4][4]; };
+__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my)
 {
-    __shared__ uint8_t sy[20][24];          /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
-    __shared__ uint8_t sc[2][12][16];       /* chroma rows / cols -4..7 */
-    __shared__ uint8_t sbs[2][4][4];
-    const FrameDev F = Fs[blockIdx.y];
-    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-    const int my = y_lo + (int)blockIdx.x, mx = d - 2 * my;
-    if (my >= F.mb_h || mx < 0 || mx >= F.mb_w) return;
+    uint8_t (*sy)[24] = D->sy;              /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
+    uint8_t (*sc)[12][16] = D->sc;          /* chroma rows / cols -4..7 */
+    uint8_t (*sbs)[4][4] = D->sbs;
     const int lane = LANE(), xy = my * F.mb_w + mx, W = F.w, CW = F.w >> 1;
     const int gx = 16 * mx, gy = 16 * my, cgx = 8 * mx, cgy = 8 * my;
     /* stage: 20 rows x 5 dwords of luma, 2 x 12 rows x 3 dwords of chroma (nothing outside the picture) */
@@ -277,6 +274,15 @@ __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict_
     if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
       *(uint32_t *)(dst + (size_t)(cgy - 4 + r) * CW + cgx + c) = *(const uint32_t *)&sc[pl][r][c + 4]; }
 }
+__global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+{
+    __shared__ DeblockLDS D;
+    const FrameDev F = Fs[blockIdx.y];
+    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int my = y_lo + (int)blockIdx.x, mx = d - 2 * my;
+    if (my >= F.mb_h || mx < 0 || mx >= F.mb_w) return;
+    mbk_deblock(F, &D, mx, my);
+}
 
 /* ------------------------------------------------------------------ dataflow scheduling of the analysis
  * One persistent launch per frame step instead of one launch per anti-diagonal: macroblock (x,y) of a
@@ -334,10 +340,11 @@ __device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot
 #ifndef PCAMV_FLOW_OCC
 #define PCAMV_FLOW_OCC 4        /* waves per SIMD the register allocation of the persistent kernel is held to */
 #endif
-__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+/* the queue protocol, shared by the two persistent kernels; MODE 0: search -> publish -> reconstruction + RCA,
+ * MODE 1: pass 2 + loop filter of the macroblock -> publish */
+template <int MODE>
+__device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const FlowDev &fl, MBLocal &L, Analysis *Ap, DeblockLDS *Dp)
 {
-    __shared__ MBLocal L;
-    __shared__ Analysis A;
     const int lane = LANE();
     /* home queue = this wave's XCD (speed only: the GOPs of one queue are then searched through one L2
      * instead of being replicated in all eight); a wave whose queue is handed out moves on to the others */
@@ -374,7 +381,12 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
         PROF_ADD(0, t_pop);
         const unsigned long long t_s = PROF_T();
-        mbk_search(F, &L, &A, x, y);
+        if (MODE == 0) mbk_search(F, &L, Ap, x, y);
+        else {
+            mbk_pass2(F, &L, x, y);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
+            mbk_deblock(F, Dp, x, y);
+        }
         PROF_ADD(1, t_s);
         const unsigned long long t_p = PROF_T();
         /* publish: stores drained, L2 written back, then the counters / queue entries */
@@ -391,12 +403,22 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
         }
         PROF_ADD(2, t_p);
         const unsigned long long t_r = PROF_T();
-        if (fl.fused) mbk_rca_encode(F, &L, &A, xy);
+        if (MODE == 0 && fl.fused) mbk_rca_encode(F, &L, Ap, xy);
         PROF_ADD(3, t_r);
         PROF_ADD(4, t_pop);
         if (LANE() == 0) { PROF_ADD(5, PROF_T() - 1); }
     }
 }
+
+__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    flow_loop<0>(Fs, fl, L, &A, nullptr);
+}
+/* (MODE 1 -- pass 2 + loop filter through the same queue -- is correct but measured slower than the per-diagonal
+ * launches: a 15 us task cannot carry an agent-scope release per macroblock, 245 vs 176 ms per closed-loop step at
+ * G=256; it would need write-through hand-off stores instead of the L2 write-back.  Not instantiated.) */
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */

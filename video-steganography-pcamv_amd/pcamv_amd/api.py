@@ -287,6 +287,13 @@ class Encoder:
         self._chk(self.lib.pcamv_gpu_recon_device(self.ctx, out), "recon_device")
         return [int(out[i]) for i in range(3)]
 
+    def fetch_recon(self):
+        W, H = self.p.i_width, self.p.i_height
+        planes = [np.zeros((H >> s, W >> s), np.uint8) for s in (0, 1, 1)]
+        arr = (C.c_void_p * 3)(*[a.ctypes.data for a in planes])
+        self._chk(self.lib.pcamv_gpu_fetch_recon(self.ctx, arr), "fetch_recon")
+        return tuple(planes)
+
     def set_fenc_device(self, y, u, v):
         self._chk(self.lib.pcamv_gpu_set_fenc_device(self.ctx, C.c_void_p(y), C.c_void_p(u), C.c_void_p(v)), "set_fenc_device")
 
