@@ -260,6 +260,8 @@ SWEEP = [
     (176, 144, "esa", 8, 2, 0x10, 28, 1, 1, 1, 0, 46, 48),       # exhaustive, subme 2
     (320, 240, "umh", 16, 5, 0x10, 24, 1, 1, 1, 0, 47, 96),      # borders of a wider picture, many skips
     (176, 144, "esa", 16, 5, 0x30, 33, 1, 1, 1, 0, 48, 32),      # exhaustive with p4x4
+    (1280, 720, "hex", 16, 5, 0x10, 26, 1, 1, 1, 0, 11, 320),    # BASELINE config 2's size and search (720p, --me hex)
+    (640, 480, "esa", 16, 5, 0x10, 26, 1, 1, 1, 0, 17, 128),     # config 5's search (--me esa) on a larger picture
 ]
 
 
