@@ -94,6 +94,18 @@ static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_
     }
     return r;
 }
+/* exhaustive window: every full-pel position in raster order, first minimum */
+static inline EvalRes prim_esa_window(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, int min_x, int min_y, int width, int nrows, int mvp0, int mvp1)
+{
+    EvalRes r = {PCAMV_COST_MAX, -1};
+    for (int ry = 0; ry < nrows; ry++)
+        for (int rx = 0; rx < width; rx++) {
+            const int mx = 4 * (min_x + rx), my = 4 * (min_y + ry);
+            const int cost = prim_cost_luma_nolog(F, L, L->fenc, ip, xoff, yoff, mx, my, 0) + F.cost_mv[mx - mvp0] + F.cost_mv[my - mvp1];
+            if (cost < r.cost) { r.cost = cost; r.idx = ry * width + rx; }
+        }
+    return r;
+}
 static inline int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {
     int ox = 4 * (i8 & 1), oy = 2 * (i8 & 2), s = 0;

@@ -380,14 +380,9 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
         const int min_x = imax(bmx - i_me_range, mv_x_min), min_y = imax(bmy - i_me_range, mv_y_min);
         const int max_x = imin(bmx + i_me_range, mv_x_max), max_y = imin(bmy + i_me_range, mv_y_max);
         const int width = (max_x - min_x + 3) & ~3;
-        const int total = width > 0 && max_y >= min_y ? width * (max_y - min_y + 1) : 0;
-        for (int base = 0; base < total; base += 64) {
-            const int n = imin(64, total - base);
-            FOR_CAND(c, n) {
-                int g = base + c, ry = g / width, rx = g - ry * width;
-                L->cxy[c] = CAND_PACK((min_x + rx) * 4, (min_y + ry) * 4);
-            }
-            fpel_fold(F, L, me, bmx, bmy, bcost, n);
+        if (width > 0 && max_y >= min_y) {
+            EvalRes r = prim_esa_window(F, L, ip, me->xoff, me->yoff, min_x, min_y, width, max_y - min_y + 1, me->mvp[0], me->mvp[1]);
+            if (r.cost < bcost) { bcost = r.cost; bmx = min_x + r.idx % width; bmy = min_y + r.idx / width; }
         }
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;

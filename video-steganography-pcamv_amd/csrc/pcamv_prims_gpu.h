@@ -350,6 +350,74 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
     return res;
 }
 
+/* Exhaustive search window (me.c:489-622 without the ADS skip, see pcamv_logic.h): SAD + MV bits of every
+ * full-pel position x in [min_x, min_x + width), y in [min_y, min_y + nrows), first minimum in raster order.
+ * lane = slot * nblk + blk: the 64/nblk slots take 64/nblk consecutive rows; along a row each lane walks x in
+ * steps of 4, fetching its four 4-pixel rows as 8 bytes once and forming the four shifted candidates with
+ * v_alignbit; the per-candidate sums of a block pair travel through the DPP butterfly packed two to a register
+ * (a 16x16 SAD is < 2^16).  key = cost << 11 | raster index (index < 2048). */
+__device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L, int ip_, int xoff_, int yoff_, int min_x_, int min_y_,
+                                                   int width_, int nrows_, int mvp0_, int mvp1_)
+{
+    const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), min_x = rfl(min_x_), min_y = rfl(min_y_), width = rfl(width_), nrows = rfl(nrows_);
+    const int mvp0 = rfl(mvp0_), mvp1 = rfl(mvp1_);
+    const int lane = LANE();
+    const int lgn = lg_nblk_of(ip), lgw = lg_w4_of(ip), nblk = 1 << lgn;
+    const int slot = lane >> lgn, blk = lane & (nblk - 1), nslot = 64 >> lgn;
+    const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
+    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    PCAMV_WAVE_SYNC();
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + (py + k) * 16 + px);
+    const gp8 lb = (gp8)F.luma_base;
+    const uint32_t stride = (uint32_t)F.stride;
+    const gp8 lb1 = lb + stride, lb2 = lb1 + stride, lb3 = lb2 + stride;
+    const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
+    int best = 0x7fffffff;
+    for (int r0 = 0; r0 < nrows; r0 += nslot) {
+        const int ry = r0 + slot;
+        const bool rowok = ry < nrows;
+        const int my = min_y + (rowok ? ry : 0);
+        const int ycost = (int)cost_tab[(uint32_t)(my * 4 - mvp1 + PCAMV_COST_MV_CENTRE)];
+        const uint32_t orow = rowbase + (uint32_t)(my * (int)stride + min_x);
+        for (int x0 = 0; x0 < width; x0 += 4) {
+            const uint32_t o = orow + (uint32_t)x0;
+            const uint64_t w0 = gld8(lb, o), w1 = gld8(lb1, o), w2 = gld8(lb2, o), w3 = gld8(lb3, o);
+            uint32_t s[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t sh = 8u * (uint32_t)j;
+                uint32_t a = 0;
+                a = __builtin_amdgcn_sad_u8(e[0], j ? __builtin_amdgcn_alignbit((uint32_t)(w0 >> 32), (uint32_t)w0, sh) : (uint32_t)w0, a);
+                a = __builtin_amdgcn_sad_u8(e[1], j ? __builtin_amdgcn_alignbit((uint32_t)(w1 >> 32), (uint32_t)w1, sh) : (uint32_t)w1, a);
+                a = __builtin_amdgcn_sad_u8(e[2], j ? __builtin_amdgcn_alignbit((uint32_t)(w2 >> 32), (uint32_t)w2, sh) : (uint32_t)w2, a);
+                a = __builtin_amdgcn_sad_u8(e[3], j ? __builtin_amdgcn_alignbit((uint32_t)(w3 >> 32), (uint32_t)w3, sh) : (uint32_t)w3, a);
+                s[j] = a;
+            }
+            int p01 = (int)(s[0] | s[1] << 16), p23 = (int)(s[2] | s[3] << 16);
+            p01 = group_sum(p01, nblk); p23 = group_sum(p23, nblk);
+            /* lane j < 4 of the group finishes candidate x0 + j (the others repeat one of them: harmless for a
+             * minimum); groups of fewer than 4 lanes finish all four in every lane */
+            const int jn = nblk >= 4 ? 1 : 4;
+            for (int jj = 0; jj < jn; jj++) {
+                const int j = nblk >= 4 ? (blk & 3) : jj;
+                const int sad = (j & 2 ? p23 : p01) >> (16 * (j & 1)) & 0xffff;
+                const int mx = min_x + x0 + j;
+                const int cost = sad + ycost + (int)cost_tab[(uint32_t)(mx * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
+                const int key = (cost << 11) | (ry * width + x0 + j);
+                if (rowok && x0 + j < width && key < best) best = key;
+            }
+        }
+    }
+    best = wave_min_i32(best);
+    EvalRes res;
+    if (best == 0x7fffffff) { res.cost = PCAMV_COST_MAX; res.idx = -1; }
+    else { res.cost = best >> 11; res.idx = best & 2047; }
+    PCAMV_WAVE_SYNC();
+    return res;
+}
+
 /* analyse.c:1535-1567: chroma cost of one 8x8 split below 8x8; mv4[k] = MV of luma 4x4 k (raster in the 8x8) */
 __device__ __forceinline__ int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {
