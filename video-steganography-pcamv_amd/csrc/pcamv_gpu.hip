@@ -397,16 +397,14 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
     }
     if (what & 8) {      /* pass 2: final MVs -> reconstruction -> loop filter, same dependency as the search */
-        /* per anti-diagonal launches: these tasks are too short for the dataflow queue's per-macroblock release */
-            for (int pass = 0; pass < 2; pass++)
-                for (int d = 0; d < b->n_diag; d++) {
-                    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-                    int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
-                    int cnt = y_hi - y_lo + 1;
-                    if (cnt <= 0) continue;
-                    if (pass == 0) hipLaunchKernelGGL(k_pass2_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
-                    else hipLaunchKernelGGL(k_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
-                }
+        /* per anti-diagonal launches (these tasks are too short for the dataflow queue's per-macroblock release) */
+        for (int d = 0; d < b->n_diag; d++) {
+            int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+            int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+            int cnt = y_hi - y_lo + 1;
+            if (cnt <= 0) continue;
+            hipLaunchKernelGGL(k_pass2_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(b, PCAMV_EHIP, "kernel launch: %s", hipGetErrorString(e));

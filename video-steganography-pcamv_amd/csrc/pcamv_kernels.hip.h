@@ -284,6 +284,22 @@ __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict_
     mbk_deblock(F, &D, mx, my);
 }
 
+/* both stages of one anti-diagonal in one launch: the filter of (x,y) only needs the pass-2 reconstruction of
+ * (x,y) itself and the filtered neighbours of earlier diagonals, and only modifies macroblocks of earlier diagonals */
+__global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+{
+    __shared__ MBLocal L;
+    __shared__ DeblockLDS D;
+    const FrameDev F = Fs[blockIdx.y];
+    int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int y = y_lo + (int)blockIdx.x, x = d - 2 * y;
+    if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
+    mbk_pass2(F, &L, x, y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
+    __syncthreads();
+    mbk_deblock(F, &D, x, y);
+}
+
 /* ------------------------------------------------------------------ dataflow scheduling of the analysis
  * One persistent launch per frame step instead of one launch per anti-diagonal: macroblock (x,y) of a
  * GOP becomes ready when (x-1,y) and (x+1,y-1) [or (x,y-1) at the right edge] are done; ready
