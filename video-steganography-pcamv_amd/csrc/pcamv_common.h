@@ -110,6 +110,7 @@ struct MBLocal {
     int16_t cmv[48][2];
     int8_t cref[48];
     int16_t pskip_mv[2];
+    int16_t mvr_own[2];            /* this macroblock's 16x16 search result as published to F.mvr */
     int mb_x, mb_y, mb_xy;
     int mv_min[2], mv_max[2], mv_min_spel[2], mv_max_spel[2], mv_min_fpel[2], mv_max_fpel[2];
     int neighbour, type_left, type_top, type_topleft, type_topright;
@@ -162,6 +163,21 @@ struct EvalRes { int cost, idx; };
 #else
 #define FOR_CAND(c, n) for (int c = (int)(threadIdx.x & 63), c##_1 = 1; c##_1 && c < (n); c##_1 = 0)
 #endif
+
+/* Stores of the bytes other wavefronts read inside the same launch (a macroblock's final motion, read by its right
+ * and lower neighbours): write-through at agent scope (`global_store ... sc1`), so that publishing them needs only the
+ * storing wave's `s_waitcnt vmcnt(0)` and not an agent-scope release, which writes back the XCD's whole dirty L2
+ * (guide 6 Guideline 16, recipe R1; the consumer keeps its agent-scope acquire). */
+#ifdef PCAMV_HOST_EMU
+#define NB_ST32(p, v) (*(uint32_t *)(p) = (uint32_t)(v))
+#define NB_ST16(p, v) (*(uint16_t *)(p) = (uint16_t)(v))
+#define NB_ST8(p, v) (*(int8_t *)(p) = (int8_t)(v))
+#else
+#define NB_ST32(p, v) __hip_atomic_store((uint32_t *)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define NB_ST16(p, v) __hip_atomic_store((uint16_t *)(p), (uint16_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define NB_ST8(p, v) __hip_atomic_store((int8_t *)(p), (int8_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+#define NB_PACK16(lo, hi) ((uint32_t)(uint16_t)(lo) | (uint32_t)(uint16_t)(hi) << 16)
 
 #ifdef PCAMV_HOST_EMU
 #define PCAMV_WAVE_SYNC() do { } while (0)

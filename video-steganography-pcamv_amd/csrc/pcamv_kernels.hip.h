@@ -405,9 +405,9 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         }
         PROF_ADD(1, t_s);
         const unsigned long long t_p = PROF_T();
-        /* publish: stores drained, L2 written back, then the counters / queue entries */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        /* publish: the motion the neighbours read was stored write-through (NB_ST*, `sc1`); once this wave's stores
+         * have drained, the counters / queue entries may follow -- no agent-scope release (it would write back the
+         * XCD's whole dirty L2 once per macroblock: measured 13.3 -> 19.9 M MB/s without it) */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const int base = g * fl.n_mb, q = g & (fl.nq - 1);

@@ -559,6 +559,7 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
     a->me16x16 = me;
     a->mvc[0][0] = me.mv[0]; a->mvc[0][1] = me.mv[1];
     prim_store_mvr(F, L, me.mv[0], me.mv[1]);
+    L->mvr_own[0] = (int16_t)me.mv[0]; L->mvr_own[1] = (int16_t)me.mv[1];
     cache_ref_set(L, 0, 0, 4, 4, 0);
     L->i_type = PCAMV_P_L0;
     return 0;

@@ -38,14 +38,13 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
         r->ref[i] = L->cref[i8]; r->mv[i][0] = L->cmv[i8][0]; r->mv[i][1] = L->cmv[i8][1];
         r->mv_stego[i][0] = r->mv_stego[i][1] = 0; r->inter_stego_cost[i] = 0;
         int x = i & 3, y = i >> 2;
-        F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
-        F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
+        NB_ST32(&F.mv[2 * (b4 + y * s4 + x)], NB_PACK16(L->cmv[SCAN8_0 + x + 8 * y][0], L->cmv[SCAN8_0 + x + 8 * y][1]));
     }
     if (PCAMV_LANE0) {
         r->i_type = L->i_type; r->i_partition = L->i_partition; r->i_qp = F.qp;
         for (int i = 0; i < 4; i++) r->i_sub_partition[i] = L->i_type == PCAMV_P_8x8 ? L->sub_part[i] : PCAMV_D_L0_8x8;
         r->pskip_mv[0] = L->pskip_mv[0]; r->pskip_mv[1] = L->pskip_mv[1];
-        if (L->i_type != PCAMV_P_SKIP) { r->mvr16[0] = F.mvr[2 * xy]; r->mvr16[1] = F.mvr[2 * xy + 1]; }
+        if (L->i_type != PCAMV_P_SKIP) { r->mvr16[0] = L->mvr_own[0]; r->mvr16[1] = L->mvr_own[1]; }
         else { r->mvr16[0] = r->mvr16[1] = 0; }
         r->used = (uint8_t)used; r->pad[0] = r->pad[1] = r->pad[2] = 0;
         for (int k = 0; k < n; k++) {
@@ -53,9 +52,9 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
             F.mvp_aux[(xy * 16 + slots[k]) * 2] = (int16_t)me->mvp[0];
             F.mvp_aux[(xy * 16 + slots[k]) * 2 + 1] = (int16_t)me->mvp[1];
         }
-        F.mb_type[xy] = (int8_t)L->i_type;
-        F.ref8[b8] = L->cref[scan8_of(0)]; F.ref8[b8 + 1] = L->cref[scan8_of(4)];
-        F.ref8[b8 + s8] = L->cref[scan8_of(8)]; F.ref8[b8 + s8 + 1] = L->cref[scan8_of(12)];
+        NB_ST8(&F.mb_type[xy], L->i_type);
+        NB_ST16(&F.ref8[b8], (uint16_t)(uint8_t)L->cref[scan8_of(0)] | (uint16_t)(uint8_t)L->cref[scan8_of(4)] << 8);
+        NB_ST16(&F.ref8[b8 + s8], (uint16_t)(uint8_t)L->cref[scan8_of(8)] | (uint16_t)(uint8_t)L->cref[scan8_of(12)] << 8);
     }
 }
 

@@ -864,6 +864,6 @@ __device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L)
 }
 __device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, int mvx, int mvy)
 {
-    if (LANE() == 0) { F.mvr[2 * L->mb_xy] = (int16_t)mvx; F.mvr[2 * L->mb_xy + 1] = (int16_t)mvy; }
+    if (LANE() == 0) NB_ST32(&F.mvr[2 * L->mb_xy], NB_PACK16(mvx, mvy));
 }
 #endif
