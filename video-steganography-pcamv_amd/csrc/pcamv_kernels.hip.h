@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__
 struct EmbedDev {
     const pcamv_mb_t *mbs; int n_mb;
     uint8_t *cover, *stego, *message; float *rho; int8_t *flip;
-    int *hdr;                 /* [0]=n [1]=m [2]=stc_ok [3]=num_flip [4]=sum(width) */
+    int *hdr;                 /* [0]=n [1]=m [2]=stc_ok [3]=num_flip [4]=sum(width) [6..7]=(double) sum of rho over the trellis */
     uint8_t *blk_which;       /* per message bit: 0 = shorter, 1 = longer sub-matrix */
     unsigned *cols;           /* [2][32] columns of the two sub-matrices; cols[64]=shorter, cols[65]=longer */
     unsigned *path;           /* n * 32 words */
@@ -475,6 +475,9 @@ struct EmbedDev {
     const uint8_t *user_message; int user_message_len;
     int cap;                  /* capacity of the per-carrier arrays */
     int *car_base;            /* [n_mb] index of each macroblock's first carrier (pass 2 finds its flips there) */
+    unsigned *colinfo;        /* per trellis column, what both Viterbi passes need of it in one word: the (shortened)
+                               * matrix column [9:0], cover bit [10], "last column of its message bit" [11], that
+                               * message bit [12].  While k_embed_prepare's schedule runs: message index << 5 | column */
 };
 
 __device__ __forceinline__ int dev_is01(int d) { return d == 0 || d == 1; }
@@ -578,124 +581,178 @@ __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restri
         base += k;
     }
     for (int i = t; i < E.cap; i += 1024) { E.stego[i] = 0; E.flip[i] = 0; }
+    /* the message (glibc rand, state staged in LDS: the generator is a serial chain and every step through global
+     * memory costs a round trip) and the sub-matrix schedule are independent serial jobs: one wave each */
+    __shared__ int s_rnd[33];
+    __shared__ int s_sched[4];
+    int m = E.emrate > 1.0f ? (int)E.emrate : (int)__fmul_rn(E.emrate, (float)n);
+    if (m < 0) m = 0;
     if (t == 0) {
-        int m = E.emrate > 1.0f ? (int)E.emrate : (int)__fmul_rn(E.emrate, (float)n);
-        if (m < 0) m = 0;
-        E.hdr[0] = n; E.hdr[1] = m; E.hdr[2] = 0; E.hdr[3] = 0; E.hdr[4] = 0;
-        for (int i = 0; i < m; i++)
-            E.message[i] = E.user_message ? (i < E.user_message_len ? E.user_message[i] : 0) : (uint8_t)(dev_glibc_rand(E.rnd) & 1);
+        E.hdr[0] = n; E.hdr[1] = m; E.hdr[3] = 0;
+        if (E.user_message) {
+            for (int i = 0; i < m; i++) E.message[i] = i < E.user_message_len ? E.user_message[i] : 0;
+        } else {
+            for (int i = 0; i < 33; i++) s_rnd[i] = E.rnd[i];
+            for (int i = 0; i < m; i++) E.message[i] = (uint8_t)(dev_glibc_rand(s_rnd) & 1);
+            for (int i = 0; i < 33; i++) E.rnd[i] = s_rnd[i];
+        }
+    }
+    if (t == 64) {
+        int st = 0, worm = 0, shorter = 0, longer = 0;
         /* sub-matrix schedule, embed.h:340-393 */
         if (m > 0 && m <= n) {
             double invalpha = (double)n / m;
-            int shorter = (int)floor(invalpha), longer = (int)ceil(invalpha);
+            shorter = (int)floor(invalpha); longer = (int)ceil(invalpha);
             if (dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + 32, E.lcg)) {
                 E.cols[64] = shorter; E.cols[65] = longer;
-                int worm = 0;
                 for (int i = 0; i < m; i++) {
-                    if (worm + longer <= (i + 1) * invalpha + 0.5) { E.blk_which[i] = 1; worm += longer; }
-                    else { E.blk_which[i] = 0; worm += shorter; }
+                    const int lng = worm + longer <= (i + 1) * invalpha + 0.5, wd = lng ? longer : shorter;
+                    E.blk_which[i] = (uint8_t)lng;
+                    for (int k = 0; k < wd; k++) E.colinfo[worm + k] = (unsigned)(i << 5 | k);
+                    worm += wd;
                 }
-                E.hdr[4] = worm;
-                E.hdr[2] = -1;          /* schedule valid, Viterbi pending */
-            }
+                st = -1;                /* schedule valid, Viterbi pending */
+            } else worm = 0;
         }
+        E.hdr[4] = worm; E.hdr[2] = st;
+        s_sched[0] = worm; s_sched[1] = shorter; s_sched[2] = longer;
+    }
+    __syncthreads();
+    /* one word per trellis column for the Viterbi passes (all threads; needs the message and the schedule) */
+    const int nproc = s_sched[0], wshort = s_sched[1], wlong = s_sched[2];
+    for (int idx = t; idx < nproc; idx += 1024) {
+        const int eb = (int)E.colinfo[idx], i2 = eb >> 5, k = eb & 31;
+        const int which = E.blk_which[i2], width = which ? wlong : wshort;
+        const int left = m - i2;                                  /* the last 10 message bits use shortened columns (embed.h:462) */
+        const unsigned colmask = left >= 10 ? 1023u : (1u << left) - 1;
+        E.colinfo[idx] = (E.cols[which * 32 + k] & colmask) | (E.cover[idx] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | (E.message[i2] ? 4096u : 0u);
+    }
+    if (t >= 960) {         /* the price of flipping everything, summed in column order like embed.h:448 (the Viterbi's
+                             * failure test compares against it): one wave, 64 loads at a time, serial adds */
+        const int l = t - 960;
+        double total = 0;
+        for (int b0 = 0; b0 < nproc; b0 += 64) {
+            const float v = b0 + l < nproc ? E.rho[b0 + l] : 0.0f;
+            const int cnt = min(64, nproc - b0);
+#pragma unroll 16
+            for (int i = 0; i < cnt; i++) total += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+        }
+        if (l == 0) *(double *)(E.hdr + 6) = total;
     }
 }
 
-/* forward Viterbi: thread = trellis state.  new[s] = min(p[s] + c_stay, p[s^col] + c_flip), path bit
- * set when the flip branch is <= (embed.h:439-467 evaluated per state; ties and infinities behave
- * identically because both formulations add and compare the same two floats). */
-__global__ void __launch_bounds__(1024) k_stc_forward(const EmbedDev *__restrict__ Es)
+/* forward Viterbi over the 1024 trellis states: new[s] = min(p[s] + c_stay, p[s^col] + c_flip), path bit set
+ * when the flip branch is <= (embed.h:439-467 evaluated per state; ties and infinities behave identically
+ * because both formulations add and compare the same two floats).  The trellis columns are a serial chain with
+ * one workgroup barrier each, and what the kernel costs is the time of one link of that chain, so:
+ *   - 1024 / NS threads x NS states (s = t + NT j): the per-column bookkeeping is paid once per wave, and a
+ *     thread's own p[s] stays in registers;
+ *   - the column's constants are fetched one column ahead;
+ *   - the fold at the end of a message bit (keep the states whose LSB is that bit, embed.h:469-480) is computed
+ *     with the bit's last column instead of in a step of its own;
+ *   - the sum of all rho the result is tested against (embed.h:448) is made by k_embed_prepare;
+ *   - the barrier waits for LDS traffic only -- __syncthreads() would also drain the path-row stores (s_waitcnt
+ *     vmcnt(0)), which nothing in this kernel reads back. */
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int NS>
+__global__ void __launch_bounds__(1024 / NS) k_stc_forward(const EmbedDev *__restrict__ Es)
 {
+    constexpr int NT = 1024 / NS, LOG_NT = NS == 1 ? 10 : NS == 2 ? 9 : 8;
     const EmbedDev E = Es[blockIdx.x];
     __shared__ float s_p[2][1024];
-    __shared__ float s_rho[256];
-    __shared__ uint8_t s_cov[256];
-    const int s = threadIdx.x, lane = s & 63, wv = s >> 6;
+    __shared__ float s_rho[2][256];
+    __shared__ unsigned s_info[2][256];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (E.hdr[2] != -1) return;
-    const int n = E.hdr[0], m = E.hdr[1], nproc = E.hdr[4];
-    const int hgt = 10;
-    const unsigned wshort = E.cols[64], wlong = E.cols[65];
-    float inf = __int_as_float(0x7F800000);
+    const int nproc = E.hdr[4];
+    typedef __attribute__((address_space(1))) unsigned long long *gp64w;
+    gp64w path = (gp64w)E.path;                         /* global_store, not flat: a flat store also counts on lgkmcnt */
+    const float inf = __int_as_float(0x7F800000);
     int cur = 0;
-    s_p[0][s] = s == 0 ? 0.0f : inf;
-    unsigned colmask = 1023;
-    double total = 0;
-    int index = 0;
-    for (int i2 = 0; i2 < m; i2++) {
-        const int which = E.blk_which[i2];
-        const int width = which ? wlong : wshort;
-        for (int k = 0; k < width; k++, index++) {
-            if ((index & 255) == 0) {
-                __syncthreads();
-                if (s < 256 && index + s < nproc) { s_rho[s] = E.rho[index + s]; s_cov[s] = E.cover[index + s]; }
-                __syncthreads();
-            }
-            const unsigned column = E.cols[which * 32 + k] & colmask;
-            const float r = s_rho[index & 255];
-            const float c1 = s_cov[index & 255] == 0 ? 0.0f : r, c2 = s_cov[index & 255] == 0 ? r : 0.0f;
-            total += r;
-            const float stay = __fadd_rn(s_p[cur][s], c1), flp = __fadd_rn(s_p[cur][s ^ column], c2);
-            const bool bit = flp <= stay;
-            s_p[cur ^ 1][s] = bit ? flp : stay;
-            unsigned long long bal = __ballot(bit);
-            if (lane == 0) *(unsigned long long *)(E.path + (size_t)index * 32 + wv * 2) = bal;
-            cur ^= 1;
-            __syncthreads();
+    float p[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) { p[j] = t + j == 0 ? 0.0f : inf; s_p[0][t + NT * j] = p[j]; }
+    if (t < 256 && t < nproc) { s_rho[0][t] = E.rho[t]; s_info[0][t] = E.colinfo[t]; }
+    __syncthreads();
+    unsigned info = s_info[0][0];
+    float r = s_rho[0][0];
+    for (int index = 0; index < nproc; index++) {
+        const int c = index & 255, buf = index >> 8 & 1;
+        if (c == 0 && t < 256) {                        /* next 256 columns' constants into the other buffer */
+            const int j = index + 256 + t;
+            if (j < nproc) { s_rho[buf ^ 1][t] = E.rho[j]; s_info[buf ^ 1][t] = E.colinfo[j]; }
         }
-        const int mb = E.message[i2] ? 1 : 0;
-        float v = s < 512 ? s_p[cur][2 * s + mb] : inf;
-        __syncthreads();
-        s_p[cur][s] = v;
-        if (m - i2 <= hgt) colmask >>= 1;
-        __syncthreads();
+        const int nx = index + 1;
+        const unsigned info_n = s_info[nx >> 8 & 1][nx & 255];
+        const float r_n = s_rho[nx >> 8 & 1][nx & 255];
+        const unsigned column = info & 1023u, xlo = (unsigned)t ^ (column & (NT - 1)), chi = column >> LOG_NT;
+        const float c1 = info & 1024u ? r : 0.0f, c2 = info & 1024u ? 0.0f : r;
+        float nv[NS];
+        unsigned long long bal = 0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const float stay = __fadd_rn(p[j], c1), flp = __fadd_rn(s_p[cur][xlo + (((unsigned)j ^ chi) << LOG_NT)], c2);
+            const bool bit = flp <= stay;
+            nv[j] = bit ? flp : stay;
+            const unsigned long long b = __ballot(bit);                 /* states NT j + 64 wv ..: 64-bit word (NT / 64) j + wv of the path row */
+            bal = lane == j ? b : bal;
+        }
+        if (lane < NS) path[(size_t)index * 16 + (NT / 64) * lane + wv] = bal;
+        if (info & 2048u) {                             /* last column of a message bit: state s continues as 2s + bit */
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                if (NT * j >= 512) { nv[j] = inf; continue; }
+                const unsigned sj = t + NT * j, t2 = (2u * sj + (info >> 12 & 1)) & 1023u;
+                const float stay2 = __fadd_rn(s_p[cur][t2], c1), flp2 = __fadd_rn(s_p[cur][t2 ^ column], c2);
+                nv[j] = sj < 512 ? (flp2 <= stay2 ? flp2 : stay2) : inf;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; j++) { p[j] = nv[j]; s_p[cur ^ 1][t + NT * j] = nv[j]; }
+        cur ^= 1;
+        LDS_BARRIER();
+        info = info_n; r = r_n;
     }
-    if (s == 0) {
-        double totalprice = s_p[cur][0];
+    if (t == 0) {
+        const double totalprice = p[0], total = *(const double *)(E.hdr + 6);
         E.hdr[2] = (totalprice >= total) ? 0 : -2;     /* -2: forward ok, backward pending */
     }
-    (void)n;
 }
 
+/* backward walk (embed.h:483-520): one wave, 64 trellis columns per round.  Their path rows sit in registers,
+ * word w of every row in lane w, so the serial walk is scalar code around one v_readlane per column; the
+ * column's constants (colinfo) come from the lane of the same number.  The walk's state is wave-uniform: the
+ * compiler keeps it in SGPRs. */
 __global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__restrict__ Es)
 {
     const EmbedDev E = Es[blockIdx.x];
-    __shared__ unsigned s_path[64][32];
-    __shared__ uint8_t s_out[64];
     const int lane = threadIdx.x;
-    const int n = E.hdr[0], m = E.hdr[1];
+    const int n = E.hdr[0];
     int nf = 0, done_upto = 0;             /* elements [0, done_upto) got their stego bit here */
     if (E.hdr[2] == -2) {
-        const int hgt = 10;
-        const unsigned wshort = E.cols[64], wlong = E.cols[65];
         int index = E.hdr[4] - 1;
         done_upto = E.hdr[4];
-        unsigned state = 0, colmask = 0;
-        int i2 = m - 1, k = (E.blk_which[i2] ? (int)wlong : (int)wshort) - 1;
+        unsigned state = 0;
         while (index >= 0) {
-            /* stage the path rows of elements [base, index] in LDS, then walk them serially */
             const int base = index >= 63 ? index - 63 : 0, cnt = index - base + 1;
-            for (int i = lane; i < cnt * 32; i += 64) s_path[i >> 5][i & 31] = E.path[(size_t)base * 32 + i];
-            __syncthreads();
-            if (lane == 0) {
-                for (int e = cnt - 1; e >= 0; e--) {
-                    const int which = E.blk_which[i2];
-                    const int width = which ? (int)wlong : (int)wshort;
-                    if (k == width - 1) {
-                        state = (state << 1) | E.message[i2];
-                        if (m - i2 <= hgt) colmask = (colmask << 1) | 1;
-                    }
-                    if (s_path[e][state >> 5] & (1u << (state & 31))) { s_out[e] = 1; state ^= E.cols[which * 32 + k] & colmask; }
-                    else s_out[e] = 0;
-                    if (--k < 0) { i2--; if (i2 >= 0) k = (E.blk_which[i2] ? (int)wlong : (int)wshort) - 1; }
+            unsigned row[64];
+#pragma unroll
+            for (int e = 0; e < 64; e++) row[e] = (e < cnt && lane < 32) ? E.path[(size_t)(base + e) * 32 + lane] : 0u;
+            const unsigned info = lane < cnt ? E.colinfo[base + lane] : 0u;
+            unsigned long long out = 0;
+#pragma unroll
+            for (int e = 63; e >= 0; e--) {
+                if (e < cnt) {
+                    const unsigned inf = __builtin_amdgcn_readlane(info, e);
+                    if (inf & 2048u) state = (state << 1) | (inf >> 12 & 1);
+                    const unsigned word = __builtin_amdgcn_readlane(row[e], (state >> 5) & 31);
+                    if (word >> (state & 31) & 1) { out |= 1ull << e; state ^= inf & 1023u; }
                 }
             }
-            __syncthreads();
             if (lane < cnt) {       /* stego bit and flip map (encoder.c:1848-1855) of this chunk */
-                int st = s_out[lane], f = E.cover[base + lane] ^ st;
+                int st = (int)(out >> lane & 1), f = (int)(info >> 10 & 1) ^ st;
                 E.stego[base + lane] = (uint8_t)st; E.flip[base + lane] = (int8_t)f; nf += f;
             }
-            __syncthreads();
             index = base - 1;
         }
     }
