@@ -364,9 +364,9 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     const FrameDev &F = b->ctx[0]->F;
     const unsigned G = (unsigned)b->n;
     if (what & 1) {
-        dim3 g((F.stride + HT_W - 1) / HT_W, (F.lines + HT_H - 1) / HT_H, G);
-        hipLaunchKernelGGL(k_hpel, g, dim3(256), 0, st, dF);
-        dim3 gc((F.cstride + 255) / 256, F.clines, 2 * G);
+        dim3 g((F.stride / 4 + HP_THREADS - 1) / HP_THREADS, (F.lines + HP_ROWS - 1) / HP_ROWS, G);
+        hipLaunchKernelGGL(k_hpel, g, dim3(HP_THREADS), 0, st, dF);
+        dim3 gc((F.cstride / 4 + 255) / 256, F.clines, 2 * G);
         hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, dF);
     }
     if (what & 2) {

@@ -30,10 +30,16 @@ __global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__restrict__
     const uint8_t *__restrict__ src = F.raw[1 + pl];
     uint8_t *__restrict__ dst = F.chroma_base[pl];
     const int w = F.w >> 1, h = F.h >> 1, cstride = F.cstride, clines = F.clines;
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    /* 4 pixels per thread; pad and width are multiples of 4, so a group is inside the picture or one replicated pixel */
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
     if (x >= cstride || y >= clines) return;
-    int sx = clip3i(x - PCAMV_CPAD, 0, w - 1), sy = clip3i(y - PCAMV_CPAD, 0, h - 1);
-    dst[(size_t)y * cstride + x] = src[(size_t)sy * w + sx];
+    const uint8_t *rowp = src + (size_t)clip3i(y - PCAMV_CPAD, 0, h - 1) * w;
+    const int gx = x - PCAMV_CPAD;
+    uint32_t v;
+    if (gx < 0 || gx >= w) v = rowp[gx < 0 ? 0 : w - 1] * 0x01010101u;
+    else if (((uintptr_t)src & 3) == 0) v = *(const uint32_t *)(rowp + gx);
+    else v = rowp[gx] | rowp[gx + 1] << 8 | rowp[gx + 2] << 16 | (uint32_t)rowp[gx + 3] << 24;
+    *(uint32_t *)(dst + (size_t)y * cstride + x) = v;
 }
 
 /* clamp to [0,255] of an already shifted value.  The empty asm keeps hipcc (ROCm 7.2) from fusing
@@ -45,64 +51,88 @@ __device__ __forceinline__ uint32_t clamp_u8(int v)
     asm volatile("" : "+v"(v));
     return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
 }
-#define HT_W 64
-#define HT_H 16
-__global__ void __launch_bounds__(256) k_hpel(const FrameDev *__restrict__ Fs)
+/* The four luma planes full / H / V / HV of the reference frame, padded (x264_frame_filter + expand_border,
+ * common/mc.c:455-507, frame.c:246-300; the filtered planes are defined 4 columns / 8 rows beyond the picture and
+ * replicated from there).  One thread = 4 horizontally adjacent output pixels, walking HP_ROWS rows down: it keeps
+ * the 6 source rows x 12 source columns its filters need in registers (three dwords a row, one new row per output
+ * row), so a source byte is fetched once per thread and never goes through LDS; every store is a full dword and a
+ * wave's stores are contiguous.  The output pixel groups are aligned with the picture (pad and width are multiples
+ * of 4), so a group is either inside the filtered domain or entirely replicated from its edge pixel. */
+#define HP_ROWS 16
+#define HP_THREADS 128
+__device__ __forceinline__ void hpel_load_row(const uint8_t *__restrict__ rowp, int eg0, int W, bool fast, uint32_t d[3])
+{
+    if (fast) {
+        const uint32_t *q = (const uint32_t *)(rowp + eg0 - 4);
+        d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (uint32_t)rowp[clip3i(eg0 - 4 + 4 * i + b, 0, W - 1)] << (8 * b);
+            d[i] = v;
+        }
+    }
+}
+__global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__restrict__ Fs)
 {
     const FrameDev &F = Fs[blockIdx.z];
     const uint8_t *__restrict__ src = F.raw[0];
     uint8_t *__restrict__ planes = F.luma_base;
     const int W = F.w, H = F.h, stride = F.stride, lines = F.lines;
-    __shared__ uint8_t s_src[HT_H + 5][HT_W + 8];
-    __shared__ int16_t s_v[HT_H][HT_W + 8];
-    const int x0 = blockIdx.x * HT_W, y0 = blockIdx.y * HT_H;          /* padded-plane coordinates */
-    const int tid = threadIdx.x;
-    /* effective picture coordinates of this tile (clamp is monotonic, so the range is contiguous) */
-    const int ex0 = clip3i(x0 - PCAMV_PAD, -4, W + 3), ey0 = clip3i(y0 - PCAMV_PAD, -8, H + 7);
-    /* stage A: source tile, columns ex0-2 .. ex0+HT_W+2, rows ey0-2 .. ey0+HT_H+2, clamped into the picture */
-    for (int i = tid; i < (HT_H + 5) * (HT_W + 5); i += 256) {
-        int r = i / (HT_W + 5), c = i - r * (HT_W + 5);
-        int sx = clip3i(ex0 - 2 + c, 0, W - 1), sy = clip3i(ey0 - 2 + r, 0, H - 1);
-        s_src[r][c] = src[(size_t)sy * W + sx];
-    }
-    __syncthreads();
-    /* stage B: unrounded vertical 6-tap for every column of the tile */
-    for (int i = tid; i < HT_H * (HT_W + 5); i += 256) {
-        int r = i / (HT_W + 5), c = i - r * (HT_W + 5);
-        int t = s_src[r][c] + s_src[r + 5][c] - 5 * (s_src[r + 1][c] + s_src[r + 4][c]) + 20 * (s_src[r + 2][c] + s_src[r + 3][c]);
-        s_v[r][c] = (int16_t)t;
-    }
-    __syncthreads();
-    /* stage C: 4 horizontally adjacent outputs per thread and plane */
+    const int x0 = 4 * (blockIdx.x * HP_THREADS + threadIdx.x), yb = blockIdx.y * HP_ROWS;
+    if (x0 >= stride) return;
+    /* first picture column of the group whose values this group shows, and which of its bytes when replicated */
+    const int gx = x0 - PCAMV_PAD, eg0 = clip3i(gx, -4, W);
+    const int rep = gx < -4 ? 0 : gx > W ? 3 : -1;
+    const bool fast = eg0 >= 4 && eg0 + 8 <= W && ((uintptr_t)src & 3) == 0;
     const size_t psz = (size_t)stride * lines;
-    const int ty = tid >> 4, tx = (tid & 15) * 4;
-    const int y = y0 + ty;
-    if (y < lines) {
-        const int ey = clip3i(y - PCAMV_PAD, -8, H + 7), r = ey - ey0;
-        uint32_t of = 0, oh = 0, ov = 0, oc = 0;
+    uint32_t w[6][3];
+    uint32_t of = 0, oh = 0, ov = 0, oc = 0;
+    int ey_prev = 0;
+    for (int y = yb; y < yb + HP_ROWS && y < lines; y++) {
+        const int ey = clip3i(y - PCAMV_PAD, -8, H + 7);
+        if (y == yb || ey != ey_prev) {
+            if (y == yb) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int x = x0 + tx + k;
-            int px = clip3i(x - PCAMV_PAD, 0, W - 1), py = clip3i(y - PCAMV_PAD, 0, H - 1);
-            int ex = clip3i(x - PCAMV_PAD, -4, W + 3), c = ex - ex0 + 2;       /* column in the tiles */
-            /* integer plane: plain replicate padding; taken from the tile when inside it, else from memory */
-            int f = src[(size_t)py * W + px];
-            const uint8_t *sr = &s_src[r + 2][c];
-            int th = sr[-2] + sr[3] - 5 * (sr[-1] + sr[2]) + 20 * (sr[0] + sr[1]);
-            const int16_t *vr = &s_v[r][c];
-            int tc = vr[-2] + vr[3] - 5 * (vr[-1] + vr[2]) + 20 * (vr[0] + vr[1]);
-            of |= (uint32_t)f << (8 * k);
-            oh |= clamp_u8((th + 16) >> 5) << (8 * k);
-            ov |= clamp_u8((vr[0] + 16) >> 5) << (8 * k);
-            oc |= clamp_u8((tc + 512) >> 10) << (8 * k);
+                for (int k = 0; k < 5; k++) hpel_load_row(src + (size_t)clip3i(ey - 2 + k, 0, H - 1) * W, eg0, W, fast, w[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) { w[k][0] = w[k + 1][0]; w[k][1] = w[k + 1][1]; w[k][2] = w[k + 1][2]; }
+            }
+            hpel_load_row(src + (size_t)clip3i(ey + 3, 0, H - 1) * W, eg0, W, fast, w[5]);
+            ey_prev = ey;
+            /* window positions 2..10 = picture columns eg0-2 .. eg0+6: unrounded vertical 6-tap of each, and row 2 itself */
+            int v[9], b2[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int q = (j + 2) >> 2, sh = 8 * ((j + 2) & 3);
+#define HPB(k) ((int)(w[k][q] >> sh & 255))
+                v[j] = HPB(0) + HPB(5) - 5 * (HPB(1) + HPB(4)) + 20 * (HPB(2) + HPB(3));
+                b2[j] = HPB(2);
+#undef HPB
+            }
+            of = w[2][1]; oh = ov = oc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int th = b2[k] + b2[k + 5] - 5 * (b2[k + 1] + b2[k + 4]) + 20 * (b2[k + 2] + b2[k + 3]);
+                const int tc = v[k] + v[k + 5] - 5 * (v[k + 1] + v[k + 4]) + 20 * (v[k + 2] + v[k + 3]);
+                oh |= clamp_u8((th + 16) >> 5) << (8 * k);
+                ov |= clamp_u8((v[k + 2] + 16) >> 5) << (8 * k);
+                oc |= clamp_u8((tc + 512) >> 10) << (8 * k);
+            }
+            if (rep >= 0) {
+                const int sh = 8 * rep;
+                of = (of >> sh & 255) * 0x01010101u; oh = (oh >> sh & 255) * 0x01010101u;
+                ov = (ov >> sh & 255) * 0x01010101u; oc = (oc >> sh & 255) * 0x01010101u;
+            }
         }
-        if (x0 + tx < stride) {
-            size_t o = (size_t)y * stride + x0 + tx;
-            *(uint32_t *)(planes + o) = of;
-            *(uint32_t *)(planes + psz + o) = oh;
-            *(uint32_t *)(planes + 2 * psz + o) = ov;
-            *(uint32_t *)(planes + 3 * psz + o) = oc;
-        }
+        const size_t o = (size_t)y * stride + x0;
+        *(uint32_t *)(planes + o) = of;
+        *(uint32_t *)(planes + psz + o) = oh;
+        *(uint32_t *)(planes + 2 * psz + o) = ov;
+        *(uint32_t *)(planes + 3 * psz + o) = oc;
     }
 }
 
@@ -631,11 +661,11 @@ __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restri
                              * failure test compares against it): one wave, 64 loads at a time, serial adds */
         const int l = t - 960;
         double total = 0;
-        for (int b0 = 0; b0 < nproc; b0 += 64) {
-            const float v = b0 + l < nproc ? E.rho[b0 + l] : 0.0f;
-            const int cnt = min(64, nproc - b0);
-#pragma unroll 16
-            for (int i = 0; i < cnt; i++) total += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+        for (int b0 = 0; b0 < nproc; b0 += 64) {        /* columns past the end add +0.0: no effect on a sum of non-negatives */
+            const double v = b0 + l < nproc ? (double)E.rho[b0 + l] : 0.0;
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+#pragma unroll
+            for (int i = 0; i < 64; i++) total += __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
         }
         if (l == 0) *(double *)(E.hdr + 6) = total;
     }
