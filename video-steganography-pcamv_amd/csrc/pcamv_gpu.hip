@@ -53,7 +53,7 @@ struct pcamv_ctx {
     int pp, prev_internal;      /* ping-pong of the motion field for device-resident chains */
     pcamv_mb_t *d_rec_mb;
     int16_t *d_cost_mv[52];
-    uint8_t *d_cover, *d_stego, *d_message, *d_blk_which, *d_user_msg; unsigned *d_colinfo;
+    uint8_t *d_cover, *d_stego, *d_message, *d_user_msg; unsigned *d_colinfo;
     float *d_rho; int8_t *d_flip; int *d_hdr, *d_rnd; unsigned *d_cols, *d_path; long long *d_lcg;
     int cap;
     int *d_trace;
@@ -242,7 +242,7 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     HIPCHK(c, hipMemset(c->d_mvp_aux, 0, (size_t)F.n_mb * 64));
     c->cap = 16 * F.n_mb;
     HIPCHK(c, dalloc(&c->d_cover, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_stego, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_message, (size_t)c->cap));
-    HIPCHK(c, dalloc(&c->d_blk_which, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_user_msg, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_colinfo, (size_t)c->cap));
+    HIPCHK(c, dalloc(&c->d_user_msg, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_colinfo, (size_t)c->cap));
     HIPCHK(c, dalloc(&c->d_rho, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_flip, (size_t)c->cap));
     HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 72)); HIPCHK(c, dalloc(&c->d_lcg, 1));
     HIPCHK(c, dalloc(&c->d_path, (size_t)c->cap * 32));
@@ -262,7 +262,7 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     F.nnz = c->d_nnz; F.car_base = c->d_car_base; F.flip = c->d_flip;
     EmbedDev &E = c->E;
     E.mbs = c->d_rec_mb; E.n_mb = F.n_mb; E.cover = c->d_cover; E.stego = c->d_stego; E.message = c->d_message; E.rho = c->d_rho;
-    E.flip = c->d_flip; E.hdr = c->d_hdr; E.blk_which = c->d_blk_which; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
+    E.flip = c->d_flip; E.hdr = c->d_hdr; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
     E.lcg = c->d_lcg; E.colinfo = c->d_colinfo; E.cap = c->cap; E.car_base = c->d_car_base; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
     pcamv_ctx *one[1] = {c};
     int rc = pcamv_gpu_batch_create(one, 1, &c->self);
@@ -282,7 +282,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
     hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb); hipFree(c->d_mv_b); hipFree(c->d_ref8_b);
     for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);
-    hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_blk_which); hipFree(c->d_colinfo); hipFree(c->d_user_msg); hipFree(c->d_rho);
+    hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_colinfo); hipFree(c->d_user_msg); hipFree(c->d_rho);
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
     if (c->d_trace) hipFree(c->d_trace);
     hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user);

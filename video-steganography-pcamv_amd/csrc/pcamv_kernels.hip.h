@@ -496,7 +496,6 @@ struct EmbedDev {
     const pcamv_mb_t *mbs; int n_mb;
     uint8_t *cover, *stego, *message; float *rho; int8_t *flip;
     int *hdr;                 /* [0]=n [1]=m [2]=stc_ok [3]=num_flip [4]=sum(width) [6..7]=(double) sum of rho over the trellis */
-    uint8_t *blk_which;       /* per message bit: 0 = shorter, 1 = longer sub-matrix */
     unsigned *cols;           /* [2][32] columns of the two sub-matrices; cols[64]=shorter, cols[65]=longer */
     unsigned *path;           /* n * 32 words */
     int *rnd;                 /* glibc rand state: r[0..30], f, b */
@@ -507,7 +506,7 @@ struct EmbedDev {
     int *car_base;            /* [n_mb] index of each macroblock's first carrier (pass 2 finds its flips there) */
     unsigned *colinfo;        /* per trellis column, what both Viterbi passes need of it in one word: the (shortened)
                                * matrix column [9:0], cover bit [10], "last column of its message bit" [11], that
-                               * message bit [12].  While k_embed_prepare's schedule runs: message index << 5 | column */
+                               * message bit [12] */
 };
 
 __device__ __forceinline__ int dev_is01(int d) { return d == 0 || d == 1; }
@@ -611,52 +610,62 @@ __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restri
         base += k;
     }
     for (int i = t; i < E.cap; i += 1024) { E.stego[i] = 0; E.flip[i] = 0; }
-    /* the message (glibc rand, state staged in LDS: the generator is a serial chain and every step through global
-     * memory costs a round trip) and the sub-matrix schedule are independent serial jobs: one wave each */
-    __shared__ int s_rnd[33];
-    __shared__ int s_sched[4];
+    /* ---- message, sub-matrix schedule (embed.h:340-393), per-column constants ----
+     * The schedule "take the longer sub-matrix while the columns used so far stay <= (i + 1) * invalpha + 0.5"
+     * has the closed form  columns before message bit i = floor(i * invalpha + 0.5)  (each step adds floor or ceil
+     * of invalpha, and the rule picks the one that lands on the next floor; tests/test_stc_schedule.py checks the
+     * two agree in the same double arithmetic), so message bits are independent and only the message itself (a
+     * lagged-Fibonacci generator) and the sum of rho stay serial, one wave each. */
+    __shared__ unsigned s_rnd[64];
+    __shared__ int s_ok;
     int m = E.emrate > 1.0f ? (int)E.emrate : (int)__fmul_rn(E.emrate, (float)n);
     if (m < 0) m = 0;
-    if (t == 0) {
-        E.hdr[0] = n; E.hdr[1] = m; E.hdr[3] = 0;
-        if (E.user_message) {
-            for (int i = 0; i < m; i++) E.message[i] = i < E.user_message_len ? E.user_message[i] : 0;
-        } else {
-            for (int i = 0; i < 33; i++) s_rnd[i] = E.rnd[i];
-            for (int i = 0; i < m; i++) E.message[i] = (uint8_t)(dev_glibc_rand(s_rnd) & 1);
-            for (int i = 0; i < 33; i++) E.rnd[i] = s_rnd[i];
-        }
-    }
+    const bool sched = m > 0 && m <= n;
+    const double invalpha = sched ? (double)n / m : 0.0;
+    const int shorter = (int)floor(invalpha), longer = (int)ceil(invalpha);
+#define STC_BEFORE(i) ((i) == 0 ? 0 : (int)floor((i) * invalpha + 0.5))
+    const int nproc = sched ? STC_BEFORE(m) : 0;
     if (t == 64) {
-        int st = 0, worm = 0, shorter = 0, longer = 0;
-        /* sub-matrix schedule, embed.h:340-393 */
-        if (m > 0 && m <= n) {
-            double invalpha = (double)n / m;
-            shorter = (int)floor(invalpha); longer = (int)ceil(invalpha);
-            if (dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + 32, E.lcg)) {
-                E.cols[64] = shorter; E.cols[65] = longer;
-                for (int i = 0; i < m; i++) {
-                    const int lng = worm + longer <= (i + 1) * invalpha + 0.5, wd = lng ? longer : shorter;
-                    E.blk_which[i] = (uint8_t)lng;
-                    for (int k = 0; k < wd; k++) E.colinfo[worm + k] = (unsigned)(i << 5 | k);
-                    worm += wd;
+        const int ok = sched && dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + 32, E.lcg);
+        if (ok) { E.cols[64] = shorter; E.cols[65] = longer; }
+        E.hdr[0] = n; E.hdr[1] = m; E.hdr[3] = 0;
+        E.hdr[4] = ok ? nproc : 0; E.hdr[2] = ok ? -1 : 0;          /* -1: schedule valid, Viterbi pending */
+        s_ok = ok;
+    }
+    if (t < 64) {
+        if (E.user_message) {
+            for (int i = t; i < m; i += 64) E.message[i] = i < E.user_message_len ? E.user_message[i] : 0;
+        } else {
+            /* glibc TYPE_3 rand(): x[k] = x[k-31] + x[k-3], output x[k] >> 1.  Three outputs are independent of each
+             * other, so lanes 0..2 make three per round on a 64-entry ring in LDS.  The stored state is a 31-entry
+             * ring with the oldest value at st[31] (f): x[-31 + j] = st[(f + j) % 31]. */
+            const int f = E.rnd[31];
+            if (t < 31) s_rnd[33 + t] = (unsigned)E.rnd[(f + t) % 31];         /* x[-31 + t] at ring position (-31 + t) & 63 */
+            PCAMV_WAVE_SYNC();
+            for (int k0 = 0; k0 < m; k0 += 3) {
+                const int k = k0 + t;
+                if (t < 3 && k < m) {
+                    const unsigned v = s_rnd[(k - 31) & 63] + s_rnd[(k - 3) & 63];
+                    s_rnd[k & 63] = v;
+                    E.message[k] = (uint8_t)(v >> 1 & 1);
                 }
-                st = -1;                /* schedule valid, Viterbi pending */
-            } else worm = 0;
+                PCAMV_WAVE_SYNC();
+            }
+            if (t < 31) E.rnd[(f + m + t) % 31] = (int)s_rnd[(m - 31 + t) & 63];
+            if (t == 0) { E.rnd[31] = (f + m) % 31; E.rnd[32] = (E.rnd[32] + m) % 31; }
         }
-        E.hdr[4] = worm; E.hdr[2] = st;
-        s_sched[0] = worm; s_sched[1] = shorter; s_sched[2] = longer;
     }
     __syncthreads();
-    /* one word per trellis column for the Viterbi passes (all threads; needs the message and the schedule) */
-    const int nproc = s_sched[0], wshort = s_sched[1], wlong = s_sched[2];
-    for (int idx = t; idx < nproc; idx += 1024) {
-        const int eb = (int)E.colinfo[idx], i2 = eb >> 5, k = eb & 31;
-        const int which = E.blk_which[i2], width = which ? wlong : wshort;
-        const int left = m - i2;                                  /* the last 10 message bits use shortened columns (embed.h:462) */
-        const unsigned colmask = left >= 10 ? 1023u : (1u << left) - 1;
-        E.colinfo[idx] = (E.cols[which * 32 + k] & colmask) | (E.cover[idx] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | (E.message[i2] ? 4096u : 0u);
+    if (!s_ok) return;
+    for (int i = t; i < m; i += 1024) {
+        const int start = STC_BEFORE(i);
+        const int which = (double)(start + longer) <= (i + 1) * invalpha + 0.5, width = which ? longer : shorter;
+        const int left = m - i;                                   /* the last 10 message bits use shortened columns (embed.h:462) */
+        const unsigned colmask = left >= 10 ? 1023u : (1u << left) - 1, msg = E.message[i] ? 4096u : 0u;
+        for (int k = 0; k < width; k++)
+            E.colinfo[start + k] = (E.cols[which * 32 + k] & colmask) | (E.cover[start + k] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | msg;
     }
+#undef STC_BEFORE
     if (t >= 960) {         /* the price of flipping everything, summed in column order like embed.h:448 (the Viterbi's
                              * failure test compares against it): one wave, 64 loads at a time, serial adds */
         const int l = t - 960;
