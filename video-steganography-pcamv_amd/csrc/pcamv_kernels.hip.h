@@ -421,7 +421,14 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
             if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
         }
         if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[16], 1u, RLX_AGENT); break; }
+#ifdef PCAMV_FLOW_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         /* drop this CU's stale L1 lines of the neighbours' motion */
+#else
+        /* no agent-scope acquire: the only data of other waves read here is the neighbours' motion, and every such
+         * load is itself an agent-scope load (NB_LD*, `sc1`) issued after the queue entry was seen -- so this CU's L1
+         * keeps its lines of the reference planes instead of losing them once per macroblock and wave */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
         const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
         const FrameDev F = Fs[g];
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;

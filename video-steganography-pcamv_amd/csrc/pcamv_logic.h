@@ -83,12 +83,12 @@ PCAMV_DEV void predict_mv_pskip(MBLocal *L, int mv[2])
 PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
 {
     int i = 0, xy = L->mb_xy, top = xy - F.mb_w;
-#define SETMV(mb) { mvc[i][0] = F.mvr[2 * (mb)]; mvc[i][1] = F.mvr[2 * (mb) + 1]; i++; }
-    if ((L->neighbour & NB_LEFT) && F.mb_type[xy - 1] != PCAMV_P_SKIP) SETMV(xy - 1);
+#define SETMV(mb) { const uint32_t w_ = NB_LD32(&F.mvr[2 * (mb)]); mvc[i][0] = (int16_t)(w_ & 0xffff); mvc[i][1] = (int16_t)(w_ >> 16); i++; }
+    if ((L->neighbour & NB_LEFT) && L->type_left != PCAMV_P_SKIP) SETMV(xy - 1);
     if (L->neighbour & NB_TOP) {
-        if (F.mb_type[top] != PCAMV_P_SKIP) SETMV(top);
-        if ((L->neighbour & NB_TOPLEFT) && F.mb_type[top - 1] != PCAMV_P_SKIP) SETMV(top - 1);
-        if (L->mb_x < F.mb_w - 1 && F.mb_type[top + 1] != PCAMV_P_SKIP) SETMV(top + 1);
+        if (L->type_top != PCAMV_P_SKIP) SETMV(top);
+        if ((L->neighbour & NB_TOPLEFT) && L->type_topleft != PCAMV_P_SKIP) SETMV(top - 1);
+        if (L->mb_x < F.mb_w - 1 && L->type_topright != PCAMV_P_SKIP) SETMV(top + 1);
     }
 #undef SETMV
     if (F.have_prev) {
@@ -115,10 +115,10 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
     L->neighbour = 0;
     L->type_left = L->type_top = L->type_topleft = L->type_topright = -1;
     int top = L->mb_xy - F.mb_w;
-    if (mb_y > 0) { L->neighbour |= NB_TOP; L->type_top = F.mb_type[top]; }
-    if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = F.mb_type[L->mb_xy - 1]; }
-    if (mb_x < F.mb_w - 1 && mb_y > 0) { L->neighbour |= NB_TOPRIGHT; L->type_topright = F.mb_type[top + 1]; }
-    if (mb_x > 0 && mb_y > 0) { L->neighbour |= NB_TOPLEFT; L->type_topleft = F.mb_type[top - 1]; }
+    if (mb_y > 0) { L->neighbour |= NB_TOP; L->type_top = NB_LD8(&F.mb_type[top]); }
+    if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = NB_LD8(&F.mb_type[L->mb_xy - 1]); }
+    if (mb_x < F.mb_w - 1 && mb_y > 0) { L->neighbour |= NB_TOPRIGHT; L->type_topright = NB_LD8(&F.mb_type[top + 1]); }
+    if (mb_x > 0 && mb_y > 0) { L->neighbour |= NB_TOPLEFT; L->type_topleft = NB_LD8(&F.mb_type[top - 1]); }
     PCAMV_WAVE_SYNC();
     FOR_CAND(i, 48) { L->cref[i] = -2; L->cmv[i][0] = 0; L->cmv[i][1] = 0; }
     PCAMV_WAVE_SYNC();
@@ -132,7 +132,7 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
         else if (i <= 4) { ok = L->neighbour & NB_TOP; c8 = SCAN8_0 - 8 + (i - 1); m4 = t4 + (i - 1); r8 = t8 + ((i - 1) >> 1); }
         else if (i == 5) { ok = L->neighbour & NB_TOPRIGHT; c8 = SCAN8_0 + 4 - 8; m4 = t4 + 4; r8 = t8 + 2; }
         else { ok = L->neighbour & NB_LEFT; c8 = SCAN8_0 - 1 + 8 * (i - 6); m4 = b4 - 1 + (i - 6) * s4; r8 = b8 - 1 + ((i - 6) >> 1) * s8; }
-        if (ok) { L->cref[c8] = F.ref8[r8]; L->cmv[c8][0] = F.mv[2 * m4]; L->cmv[c8][1] = F.mv[2 * m4 + 1]; }
+        if (ok) { const uint32_t w_ = NB_LD32(&F.mv[2 * m4]); L->cref[c8] = NB_LD8(&F.ref8[r8]); L->cmv[c8][0] = (int16_t)(w_ & 0xffff); L->cmv[c8][1] = (int16_t)(w_ >> 16); }
     }
     PCAMV_WAVE_SYNC();
     int pm[2];
