@@ -130,8 +130,9 @@ def main():
     if prof is not None:
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 0)
         nmb = args.gops * n_mb * args.steps
-        names = ["pop+wait+acquire", "search", "publish", "reconstruct+RCA", "whole iteration"]
-        print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(5)}, file=sys.stderr)
+        names = ["pop+wait", "search", "publish", "reconstruct+RCA", "whole iteration", "-", "16x16 (+skip probe)", "8x8", "sub8x8 + 16x8 + 8x16",
+                 "final qpel refine", "reconstruction", "neighbour load", "record store"]
+        print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
     # dominant kernel: average duration of one launch, HIP events on its own stream
     dom = batch.dominant_kernel()
     avg_ms, n_launch = batch.kernel_time(reset=False)

@@ -341,14 +341,6 @@ __global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__res
  * residency or on workgroup->XCD placement: an entry index is only waited for after it was handed out,
  * entries are appended by waves that are running, and the dependency graph always has a ready node
  * until everything is done.  Spins are bounded; a timeout raises ctr[2] and every wave drains. */
-#ifdef PCAMV_PROF
-__device__ unsigned long long pcamv_prof[16];     /* diagnostics build: wave cycles per phase of k_analyse_flow */
-#define PROF_T() __builtin_readcyclecounter()
-#define PROF_ADD(i, t0) do { if (LANE() == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(PROF_T() - (t0))); } while (0)
-#else
-#define PROF_T() 0ull
-#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
-#endif
 struct FlowDev {
     unsigned *ctr;            /* [0..7] pop index of queue x, [8..15] append index of queue x, [16] error flag */
     unsigned *queue;          /* total entries, queue x at [qbase[x], qbase[x] + qcount[x]); 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
@@ -397,10 +389,16 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     int home = (int)(xcc & 7u) & (fl.nq - 1), tried = 0;
+    /* the queue ticket of the next macroblock is taken before the RCA step of the current one (nothing there depends
+     * on other waves), so the atomic's round trip is covered by work instead of being waited for (measured +2 %;
+     * reading the queue entry early as well gave nothing more) */
+    unsigned ticket = 0;
+    bool have_ticket = false;
     for (;;) {
         const unsigned long long t_pop = PROF_T();
-        unsigned idx = 0;
-        if (lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
+        unsigned idx = ticket;
+        if (!have_ticket && lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
+        have_ticket = false;
         idx = flow_bcast(idx);
         if (idx >= fl.qcount[home]) {                      /* this queue is handed out: next one, or done */
             if (++tried >= fl.nq) break;
@@ -456,7 +454,11 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         }
         PROF_ADD(2, t_p);
         const unsigned long long t_r = PROF_T();
-        if (MODE == 0 && fl.fused) mbk_rca_encode(F, &L, Ap, xy);
+        if (MODE == 0 && fl.fused) {
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
+            have_ticket = true;
+            mbk_rca_encode(F, &L, Ap, xy);
+        }
         PROF_ADD(3, t_r);
         PROF_ADD(4, t_pop);
         if (LANE() == 0) { PROF_ADD(5, PROF_T() - 1); }

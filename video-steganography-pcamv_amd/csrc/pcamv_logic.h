@@ -771,6 +771,7 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
 {
     int b_skip = 0, b_try_pskip = 0, i_cost;
     unsigned flags = F.inter;
+    const unsigned long long t_a = PROF_T();
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
     L->i_partition = PCAMV_D_16x16;
     if (F.b_fast_pskip) {
@@ -780,8 +781,12 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
     }
     if (b_skip) { L->i_type = PCAMV_P_SKIP; L->i_partition = PCAMV_D_16x16; }
     else if (!analyse_p16x16(F, L, a, b_try_pskip)) {
+        PROF_ADD(6, t_a);
         int i_type = PCAMV_P_L0, i_partition = PCAMV_D_16x16;
+        const unsigned long long t_b = PROF_T();
         if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8(F, L, a);
+        PROF_ADD(7, t_b);
+        const unsigned long long t_c = PROF_T();
         i_cost = a->me16x16.cost;
         if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost) {
             if (flags & PCAMV_ANALYSE_PSUB8x8) {
@@ -809,6 +814,8 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
             if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
         }
         L->i_partition = i_partition;
+        PROF_ADD(8, t_c);
+        const unsigned long long t_d = PROF_T();
         if (i_partition == PCAMV_D_16x16) me_refine_qpel(F, L, &a->me16x16);
         else if (i_partition == PCAMV_D_16x8) { me_refine_qpel(F, L, &a->me16x8[0]); me_refine_qpel(F, L, &a->me16x8[1]); }
         else if (i_partition == PCAMV_D_8x16) { me_refine_qpel(F, L, &a->me8x16[0]); me_refine_qpel(F, L, &a->me8x16[1]); }
@@ -821,6 +828,7 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
                 default: for (int k = 0; k < 4; k++) me_refine_qpel(F, L, &a->me4x4[i][k]); break;
                 }
         L->i_type = i_type;
+        PROF_ADD(9, t_d);
     }
     update_cache(L, a);
 }

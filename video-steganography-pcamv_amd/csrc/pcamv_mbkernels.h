@@ -22,8 +22,11 @@
 
 PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
 {
+    const unsigned long long t_l = PROF_T();
     mb_load(F, L, mb_x, mb_y);
+    PROF_ADD(11, t_l);
     analyse_mb_search(F, L, a);
+    const unsigned long long t_w = PROF_T();
     const int xy = L->mb_xy;
     int *slots = L->slots;
     const int used = F.embed && L->i_type != PCAMV_P_SKIP;
@@ -56,6 +59,7 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
         NB_ST16(&F.ref8[b8], (uint16_t)(uint8_t)L->cref[scan8_of(0)] | (uint16_t)(uint8_t)L->cref[scan8_of(4)] << 8);
         NB_ST16(&F.ref8[b8 + s8], (uint16_t)(uint8_t)L->cref[scan8_of(8)] | (uint16_t)(uint8_t)L->cref[scan8_of(12)] << 8);
     }
+    PROF_ADD(12, t_w);
 }
 
 /* rebuild the decided partitioning (types, MVs, search-time mvp) from the record */
@@ -98,13 +102,19 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
  * every carrier's replacement-MV cost.  The reconstruction of the macroblock as decided is also the
  * first re-encode of every carrier's RCA step, so it is made once (L->recb0); rca_mv_cost leaves the
  * decided MVs and the cache as it found them, so one rebuild of the analysis serves all carriers. */
-PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
 {
-    int *slots = L->slots;
-    const int n = analysis_from_record(F, L, a, xy, slots);
+    const unsigned long long t_e = PROF_T();
+    const int n = analysis_from_record(F, L, a, xy, L->slots);
     update_cache(L, a);
     mb_encode(F, L);
     prim_store_rec(F, L);
+    PROF_ADD(10, t_e);
+    return n;
+}
+PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int n)
+{
+    int *slots = L->slots;
     if (F.rec_mb[xy].used && n > 0) {
         prim_copy_pred(L, L->recb0);
         /* a 16x16 macroblock whose RCA neighbourhood (+-3 quarter pels) needs no MV clipping reads its
@@ -126,6 +136,10 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
             }
         }
     }
+}
+PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+{
+    mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy));
 }
 
 /* pass 2 of one macroblock (analyse.c:2870-3107 + x264_macroblock_encode, semantics of DESIGN.md 5b): the
