@@ -32,7 +32,7 @@ struct pcamv_batch {
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
-    int sched_flow, flow_waves, closed_loop;
+    int sched_flow, flow_waves, flow2_waves, closed_loop;
     unsigned *d_flow;
     FlowDev fl;
     char err[256];
@@ -155,8 +155,8 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     b->sched_flow = !(sched && !strcmp(sched, "diag")) && F.n_mb <= 65535 && n <= 65535;
     if (e == hipSuccess && b->sched_flow) {
         const size_t total = (size_t)n * F.n_mb;
-        e = dalloc(&b->d_flow, 32 + 2 * total);
-        b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + 32; b->fl.dep = (int *)(b->d_flow + 32 + total);
+        e = dalloc(&b->d_flow, FLOW_CTR_WORDS + 2 * total);
+        b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + FLOW_CTR_WORDS; b->fl.dep = (int *)(b->d_flow + FLOW_CTR_WORDS + total);
         const char *aff = getenv("PCAMV_FLOW_AFFINITY");
         b->fl.nq = (aff && !strcmp(aff, "0")) || n < 8 ? 1 : 8;
         unsigned qb = 0;
@@ -174,6 +174,12 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         if (waves < 1) waves = 1;
         if ((size_t)waves > total) waves = (long)total;
         b->flow_waves = (int)waves;
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass2_deblock_flow, 64, 0);
+        waves = wv ? atol(wv) : (long)per_cu * n_cu;
+        if (waves < 1) waves = 1;
+        if ((size_t)waves > total) waves = (long)total;
+        b->flow2_waves = (int)waves;
+        if (e == hipSuccess) e = hipMemset(b->d_flow, 0, FLOW_CTR_WORDS * sizeof(unsigned));
     }
     if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
     *out = b;
@@ -398,13 +404,17 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
     }
     if (what & 8) {      /* pass 2: final MVs -> reconstruction -> loop filter, same dependency as the search */
-        /* per anti-diagonal launches (these tasks are too short for the dataflow queue's per-macroblock release) */
-        for (int d = 0; d < b->n_diag; d++) {
-            int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-            int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
-            int cnt = y_hi - y_lo + 1;
-            if (cnt <= 0) continue;
-            hipLaunchKernelGGL(k_pass2_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+        if (b->sched_flow) {
+            hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
+            hipLaunchKernelGGL(k_pass2_deblock_flow, dim3(b->flow2_waves), dim3(64), 0, st, dF, b->fl);
+        } else {
+            for (int d = 0; d < b->n_diag; d++) {
+                int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+                int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
+                int cnt = y_hi - y_lo + 1;
+                if (cnt <= 0) continue;
+                hipLaunchKernelGGL(k_pass2_deblock_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+            }
         }
     }
     hipError_t e = hipGetLastError();
@@ -416,8 +426,11 @@ static int flow_check(pcamv_batch *b)
 {
     if (!b || !b->sched_flow) return 0;
     unsigned bad = 0;
-    HIPCHKB(b, hipMemcpy(&bad, b->fl.ctr + 16, sizeof(bad), hipMemcpyDeviceToHost));
-    if (bad) return bfail(b, PCAMV_EHIP, "k_analyse_flow: queue wait timed out (results of the last step are incomplete)");
+    HIPCHKB(b, hipMemcpy(&bad, b->fl.ctr + FLOW_ERR, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad) {
+        hipMemset(b->fl.ctr + FLOW_ERR, 0, sizeof(unsigned));
+        return bfail(b, PCAMV_EHIP, "dataflow kernel: queue wait timed out (results of the last step are incomplete)");
+    }
     return 0;
 }
 static int ctx_launch(pcamv_ctx *c, int what)

@@ -206,14 +206,14 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     /* stage: 20 rows x 5 dwords of luma, 2 x 12 rows x 3 dwords of chroma (nothing outside the picture) */
     for (int i = lane; i < 100; i += 64) {
         const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
-        if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = *(const uint32_t *)(F.rec[0] + (size_t)(gy + r) * W + gx + c);
+        if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = NB_LD32(F.rec[0] + (size_t)(gy + r) * W + gx + c);
     }
     for (int i = lane; i < 72; i += 64) {
         const int pl = i / 36, j = i % 36, r = j / 3 - 4, c = (j % 3) * 4 - 4;
-        if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = *(const uint32_t *)((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
+        if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
     }
     /* boundary strengths */
-    const int type = F.mb_type[xy], qp = F.qp;
+    const int type = NB_LD8(&F.mb_type[xy]), qp = F.qp;
     const int qp_thresh = 15 - (F.chroma_qp_offset > 0 ? F.chroma_qp_offset : 0);
     const int edge_end = (type == PCAMV_P_SKIP || qp <= qp_thresh) ? 1 : 4;
     const int no_sub8x8 = type != PCAMV_P_8x8 || !(F.inter & PCAMV_ANALYSE_PSUB8x8);
@@ -226,12 +226,13 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
             const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
             const int nxy = edge ? xy : (dir ? xy - F.mb_w : xy - 1);
             const int bi = (x & 1) + 2 * (y & 1) + 4 * (x >> 1) + 8 * (y >> 1), bn = (xn & 1) + 2 * (yn & 1) + 4 * (xn >> 1) + 8 * (yn >> 1);
-            if (((F.nnz[xy] >> bi) & 1) || ((F.nnz[nxy] >> bn) & 1)) bs = 2;
+            if (((NB_LD16(&F.nnz[xy]) >> bi) & 1) || ((NB_LD16(&F.nnz[nxy]) >> bn) & 1)) bs = 2;
             else if (!(edge & no_sub8x8)) {
                 const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
                 const int fx = 4 * mx + x, fy = 4 * my + y, fxn = dir == 0 ? fx - 1 : fx, fyn = dir == 0 ? fy : fy - 1;
-                const int16_t *a = F.mv + 2 * (fy * s4 + fx), *b = F.mv + 2 * (fyn * s4 + fxn);
-                if (F.ref8[(fy >> 1) * s8 + (fx >> 1)] != F.ref8[(fyn >> 1) * s8 + (fxn >> 1)] || iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4) bs = 1;
+                const uint32_t wa = NB_LD32(F.mv + 2 * (fy * s4 + fx)), wb = NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
+                const int a0 = (int16_t)(wa & 0xffff), a1 = (int16_t)(wa >> 16), b0 = (int16_t)(wb & 0xffff), b1 = (int16_t)(wb >> 16);
+                if (NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]) != NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]) || iabs(a0 - b0) >= 4 || iabs(a1 - b1) >= 4) bs = 1;
                 bs |= 0x10;              /* marks "decided by the motion test" for the copy rule below */
             }
         }
@@ -289,20 +290,20 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
         }
     /* write back: the macroblock, the 4 columns left of it (rows 0..15), the 4 rows above it (cols 0..15) */
     { const int r = lane >> 2, c = (lane & 3) * 4;
-      *(uint32_t *)(F.rec[0] + (size_t)(gy + r) * W + gx + c) = *(const uint32_t *)&sy[r + 4][c + 4]; }
-    if (lane < 16 && mx > 0) *(uint32_t *)(F.rec[0] + (size_t)(gy + lane) * W + gx - 4) = *(const uint32_t *)&sy[lane + 4][0];
+      NB_ST32(F.rec[0] + (size_t)(gy + r) * W + gx + c, *(const uint32_t *)&sy[r + 4][c + 4]); }
+    if (lane < 16 && mx > 0) NB_ST32(F.rec[0] + (size_t)(gy + lane) * W + gx - 4, *(const uint32_t *)&sy[lane + 4][0]);
     if (lane >= 16 && lane < 32 && my > 0) { const int r = (lane - 16) >> 2, c = ((lane - 16) & 3) * 4;
-      *(uint32_t *)(F.rec[0] + (size_t)(gy - 4 + r) * W + gx + c) = *(const uint32_t *)&sy[r][c + 4]; }
+      NB_ST32(F.rec[0] + (size_t)(gy - 4 + r) * W + gx + c, *(const uint32_t *)&sy[r][c + 4]); }
     if (lane >= 32) {
         const int pl = (lane - 32) >> 4, j = (lane - 32) & 15, r = j >> 1, c = (j & 1) * 4;
         uint8_t *dst = pl ? F.rec[2] : F.rec[1];
-        *(uint32_t *)(dst + (size_t)(cgy + r) * CW + cgx + c) = *(const uint32_t *)&sc[pl][r + 4][c + 4];
+        NB_ST32(dst + (size_t)(cgy + r) * CW + cgx + c, *(const uint32_t *)&sc[pl][r + 4][c + 4]);
     }
     __syncthreads();
     if (lane < 16 && mx > 0) { const int pl = lane >> 3, r = lane & 7; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
-      *(uint32_t *)(dst + (size_t)(cgy + r) * CW + cgx - 4) = *(const uint32_t *)&sc[pl][r + 4][0]; }
+      NB_ST32(dst + (size_t)(cgy + r) * CW + cgx - 4, *(const uint32_t *)&sc[pl][r + 4][0]); }
     if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
-      *(uint32_t *)(dst + (size_t)(cgy - 4 + r) * CW + cgx + c) = *(const uint32_t *)&sc[pl][r][c + 4]; }
+      NB_ST32(dst + (size_t)(cgy - 4 + r) * CW + cgx + c, *(const uint32_t *)&sc[pl][r][c + 4]); }
 }
 __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
@@ -342,7 +343,10 @@ __global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__res
  * entries are appended by waves that are running, and the dependency graph always has a ready node
  * until everything is done.  Spins are bounded; a timeout raises ctr[2] and every wave drains. */
 struct FlowDev {
-    unsigned *ctr;            /* [0..7] pop index of queue x, [8..15] append index of queue x, [16] error flag */
+    unsigned *ctr;            /* FLOW_HEAD(q) pop index / FLOW_TAIL(q) append index of queue q, FLOW_ERR error flag -- every
+                               * counter in a 128-byte line of its own: they are the hottest addresses of the launch, and
+                               * with all sixteen in one line every pop and append of the whole chip serialised on it
+                               * (23 ns per macroblock: the entire cost of the pass-2 kernel, and a floor under the search) */
     unsigned *queue;          /* total entries, queue x at [qbase[x], qbase[x] + qcount[x]); 0 = not yet published, else (gop << 16 | mb_xy) + 1 */
     int *dep;                 /* [n_gop * n_mb] dependencies still open */
     unsigned total, spin_limit;
@@ -350,6 +354,10 @@ struct FlowDev {
     int n_gop, n_mb, mb_w, mb_h, fused, nq;      /* nq = 8: GOP g lives in queue g & 7 (XCD affinity); nq = 1: one queue */
 };
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define FLOW_HEAD(q) (64 * (q))
+#define FLOW_TAIL(q) (64 * (q) + 32)
+#define FLOW_ERR 512
+#define FLOW_CTR_WORDS 576
 
 __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
 {
@@ -363,14 +371,14 @@ __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
     while (q + 1 < fl.nq && i >= fl.qbase[q + 1]) q++;
     const unsigned k = i - fl.qbase[q], ngop_q = fl.qcount[q] / (unsigned)fl.n_mb;
     fl.queue[i] = k < ngop_q ? ((k * (unsigned)fl.nq + (unsigned)q) << 16) + 1u : 0u;
-    if (i < 17) fl.ctr[i] = (i >= 8 && i < 16) ? fl.qcount[i - 8] / (unsigned)fl.n_mb : 0u;     /* heads 0, tails = GOPs of the queue, error 0 */
+    if (i < 8) { fl.ctr[FLOW_HEAD(i)] = 0u; fl.ctr[FLOW_TAIL(i)] = fl.qcount[i] / (unsigned)fl.n_mb; }     /* heads 0, tails = GOPs of the queue; the error flag is the host's */
 }
 
 __device__ __forceinline__ unsigned flow_bcast(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot, unsigned item)
 {
     if (__hip_atomic_fetch_sub(&fl.dep[slot], 1, RLX_AGENT) == 1) {
-        unsigned t = __hip_atomic_fetch_add(&fl.ctr[8 + q], 1u, RLX_AGENT);
+        unsigned t = __hip_atomic_fetch_add(&fl.ctr[FLOW_TAIL(q)], 1u, RLX_AGENT);
         __hip_atomic_store(&fl.queue[fl.qbase[q] + t], item, RLX_AGENT);
     }
 }
@@ -397,7 +405,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
     for (;;) {
         const unsigned long long t_pop = PROF_T();
         unsigned idx = ticket;
-        if (!have_ticket && lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
+        if (!have_ticket && lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
         have_ticket = false;
         idx = flow_bcast(idx);
         if (idx >= fl.qcount[home]) {                      /* this queue is handed out: next one, or done */
@@ -414,11 +422,11 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
             item = flow_bcast(v);
             if (item) break;
             unsigned bad = 0;
-            if ((spins & 255u) == 255u) { if (lane == 0) bad = __hip_atomic_load(&fl.ctr[16], RLX_AGENT); bad = flow_bcast(bad); }
+            if ((spins & 255u) == 255u) { if (lane == 0) bad = __hip_atomic_load(&fl.ctr[FLOW_ERR], RLX_AGENT); bad = flow_bcast(bad); }
             if (bad || spins >= fl.spin_limit) break;
             if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
         }
-        if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[16], 1u, RLX_AGENT); break; }
+        if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[FLOW_ERR], 1u, RLX_AGENT); break; }
 #ifdef PCAMV_FLOW_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         /* drop this CU's stale L1 lines of the neighbours' motion */
 #else
@@ -430,15 +438,19 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
         const FrameDev F = Fs[g];
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
-        PROF_ADD(0, t_pop);
+        PROF_ADD(MODE ? 13 : 0, t_pop);
         const unsigned long long t_s = PROF_T();
         if (MODE == 0) mbk_search(F, &L, Ap, x, y);
         else {
+#ifndef X_NOPASS2
             mbk_pass2(F, &L, x, y);
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
+#ifndef X_NODEBLOCK
             mbk_deblock(F, Dp, x, y);
+#endif
         }
-        PROF_ADD(1, t_s);
+        PROF_ADD(MODE ? 14 : 1, t_s);
         const unsigned long long t_p = PROF_T();
         /* publish: the motion the neighbours read was stored write-through (NB_ST*, `sc1`); once this wave's stores
          * have drained, the counters / queue entries may follow -- no agent-scope release (it would write back the
@@ -452,16 +464,15 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
                 if (x == fl.mb_w - 1) flow_done_one(fl, q, base + xy + fl.mb_w, item + (unsigned)fl.mb_w);
             }
         }
-        PROF_ADD(2, t_p);
+        PROF_ADD(MODE ? 15 : 2, t_p);
         const unsigned long long t_r = PROF_T();
         if (MODE == 0 && fl.fused) {
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[home], 1u, RLX_AGENT);
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
             have_ticket = true;
             mbk_rca_encode(F, &L, Ap, xy);
         }
         PROF_ADD(3, t_r);
-        PROF_ADD(4, t_pop);
-        if (LANE() == 0) { PROF_ADD(5, PROF_T() - 1); }
+        if (MODE == 0) PROF_ADD(4, t_pop);
     }
 }
 
@@ -471,9 +482,16 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
     __shared__ Analysis A;
     flow_loop<0>(Fs, fl, L, &A, nullptr);
 }
-/* (MODE 1 -- pass 2 + loop filter through the same queue -- is correct but measured slower than the per-diagonal
- * launches: a 15 us task cannot carry an agent-scope release per macroblock, 245 vs 176 ms per closed-loop step at
- * G=256; it would need write-through hand-off stores instead of the L2 write-back.  Not instantiated.) */
+/* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
+ * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the
+ * filter reads its neighbourhood with agent-scope loads (NB_LD*).  (With an agent-scope release + acquire per
+ * macroblock this was slower than one launch per anti-diagonal: 245 vs 176 ms per closed-loop step at G=256.) */
+__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+{
+    __shared__ MBLocal L;
+    __shared__ DeblockLDS D;
+    flow_loop<1>(Fs, fl, L, nullptr, &D);
+}
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */

@@ -173,18 +173,23 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
         PCAMV_WAVE_SYNC();
     }
     mb_encode(F, L);
+#ifdef PCAMV_HOST_EMU
     prim_store_rec(F, L);
+#else
+    prim_store_rec(F, L, true);
+#endif
+    /* final motion, type and non-zero flags: read by the neighbours' skip prediction and loop filter in the same
+     * launch, so stored write-through like the search's hand-off */
     const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
     PCAMV_WAVE_SYNC();
     FOR_CAND(i, 16) {
         int x = i & 3, y = i >> 2;
-        F.mv[2 * (b4 + y * s4 + x)] = L->cmv[SCAN8_0 + x + 8 * y][0];
-        F.mv[2 * (b4 + y * s4 + x) + 1] = L->cmv[SCAN8_0 + x + 8 * y][1];
+        NB_ST32(&F.mv[2 * (b4 + y * s4 + x)], NB_PACK16(L->cmv[SCAN8_0 + x + 8 * y][0], L->cmv[SCAN8_0 + x + 8 * y][1]));
     }
     if (PCAMV_LANE0) {
-        F.mb_type[xy] = (int8_t)L->i_type;
-        F.ref8[b8] = F.ref8[b8 + 1] = F.ref8[b8 + s8] = F.ref8[b8 + s8 + 1] = 0;
-        F.nnz[xy] = (uint16_t)L->nnz_mask;
+        NB_ST8(&F.mb_type[xy], L->i_type);
+        NB_ST16(&F.ref8[b8], 0); NB_ST16(&F.ref8[b8 + s8], 0);
+        NB_ST16(&F.nnz[xy], L->nnz_mask);
     }
 }
 

@@ -851,15 +851,20 @@ __device__ __forceinline__ void prim_copy_pred(MBLocal *L, uint8_t *dst)
     if (lane < 32) ((uint32_t *)dst)[64 + lane] = ((const uint32_t *)L->pred)[64 + lane];
     PCAMV_WAVE_SYNC();
 }
-__device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L)
+/* wt: store write-through (agent scope), for pixels another wave reads in the same launch (pass 2 -> loop filter) */
+__device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L, bool wt = false)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     { int row = lane >> 2, c4 = lane & 3;
-      *(uint32_t *)(F.rec[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4) = lds4(L->pred + row * 16 + c4 * 4); }
+      uint32_t *d = (uint32_t *)(F.rec[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4);
+      const uint32_t v = lds4(L->pred + row * 16 + c4 * 4);
+      if (wt) NB_ST32(d, v); else *d = v; }
     if (lane < 32) {
         int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
-        *(uint32_t *)((plane ? F.rec[2] : F.rec[1]) + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4) = lds4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4);
+        uint32_t *d = (uint32_t *)((plane ? F.rec[2] : F.rec[1]) + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4);
+        const uint32_t v = lds4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4);
+        if (wt) NB_ST32(d, v); else *d = v;
     }
 }
 __device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, int mvx, int mvy)
