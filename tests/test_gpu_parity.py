@@ -349,25 +349,27 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     enc.close(); o.close(); o2.close()
 
 
-def test_closed_loop_batch_step_matches_oracle(pc):
-    """two GOPs advanced together through two closed-loop steps (dataflow analysis, embedding, then pass 2 + loop
-    filter in anti-diagonal launches; the second step's reference is the first step's deblocked picture
-    and final motion field, both taken from the device): records, embedding and deblocked pictures vs the oracle"""
+@pytest.mark.parametrize("n_gops", [2, 16])
+def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
+    """GOPs advanced together through two closed-loop steps (dataflow analysis, embedding, then pass 2 + loop
+    filter through the same dataflow queue; the second step's reference is the first step's deblocked picture
+    and final motion field, both taken from the device): records, embedding and deblocked pictures vs the oracle.
+    16 GOPs = one queue per XCD, hand-offs inside and across XCDs (2 GOPs share a single queue)."""
     import torch
     import orc
     from pcamv_amd.synth import make_clip
     W, H, qp = 352, 288, 30
-    clips = [make_clip(W, H, 3, seed=61 + g, static_cols=64 * g) for g in range(2)]
+    clips = [make_clip(W, H, 3, seed=61 + g, static_cols=64 * (g % 3)) for g in range(n_gops)]
     dev = torch.device("cuda", 0)
     d = [[[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip] for clip in clips]
     mvr = pc.level_mv_range(W, H)
     p = _params(pc, W, H, pc.ME_NAMES["hex"], 5, 0x10, mvr)
-    encs = [pc.Encoder(p) for _ in range(2)]
+    encs = [pc.Encoder(p) for _ in range(n_gops)]
     batch = pc.Batch(encs)
     batch.set_closed_loop(True)
-    oracles = [orc.Oracle(orc.make_params(W, H, me="hex", subme=5, mv_range=mvr)) for _ in range(2)]
-    refs = [clips[g][0] for g in range(2)]
-    prevs = [(None, None), (None, None)]
+    oracles = [orc.Oracle(orc.make_params(W, H, me="hex", subme=5, mv_range=mvr)) for _ in range(n_gops)]
+    refs = [clips[g][0] for g in range(n_gops)]
+    prevs = [(None, None)] * n_gops
     for t in (1, 2):
         for g, enc in enumerate(encs):
             if t == 1:      # (the internal field of a fresh context holds no motion: same as no previous frame)
