@@ -180,7 +180,9 @@ int pcamv_gpu_fetch_results(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb, pcamv_embed_t 
  * which ready macroblocks of all GOPs flow through a device queue (search -> publish motion ->
  * RCA costs -> reconstruction per macroblock); with PCAMV_SCHED=diag in the environment at
  * batch/context creation, one launch per anti-diagonal ("k_search_diag") followed by RCA and
- * reconstruction launches.  Results are identical; kernel_time takes the name of the active one. */
+ * reconstruction launches.  Results are identical; kernel_time takes the name of the active one.
+ * The closed loop's second pass (pass 2 + loop filter) follows the same choice: one persistent launch
+ * ("k_pass2_deblock_flow") through the same queue, or one launch per anti-diagonal. */
 int  pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_batch_t **batch);
 void pcamv_gpu_batch_destroy(pcamv_batch_t *batch);
 int  pcamv_gpu_batch_step(pcamv_batch_t *batch, int qp, float emrate, void *stream);
