@@ -175,13 +175,6 @@ struct EvalRes { int cost, idx; };
 #define NB_LD32(p) (*(const uint32_t *)(p))
 #define NB_LD8(p) (*(const int8_t *)(p))
 #define NB_LD16(p) (*(const uint16_t *)(p))
-#elif defined(X_PLAIN)
-#define NB_ST32(p, v) (*(uint32_t *)(p) = (uint32_t)(v))
-#define NB_ST16(p, v) (*(uint16_t *)(p) = (uint16_t)(v))
-#define NB_ST8(p, v) (*(int8_t *)(p) = (int8_t)(v))
-#define NB_LD32(p) (*(const uint32_t *)(p))
-#define NB_LD8(p) (*(const int8_t *)(p))
-#define NB_LD16(p) (*(const uint16_t *)(p))
 #else
 #define NB_ST32(p, v) __hip_atomic_store((uint32_t *)(p), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define NB_ST16(p, v) __hip_atomic_store((uint16_t *)(p), (uint16_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)

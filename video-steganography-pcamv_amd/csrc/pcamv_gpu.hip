@@ -34,7 +34,7 @@ struct pcamv_batch {
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
     int sched_flow, flow_waves, flow2_waves, closed_loop;
     unsigned *d_flow;
-    FlowDev fl;
+    FlowDev fl, fl2;          /* queue descriptors of the analysis and of the second pass */
     char err[256];
 };
 
@@ -165,7 +165,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
             b->fl.qbase[q] = qb; b->fl.qcount[q] = ng * (unsigned)F.n_mb; qb += b->fl.qcount[q];
         }
         b->fl.total = (unsigned)total; b->fl.spin_limit = 4u << 20;
-        b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1;
+        b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1; b->fl.unit = 1;
         int per_cu = 0, n_cu = 0;
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow, 64, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device);
@@ -178,6 +178,16 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         waves = wv ? atol(wv) : (long)per_cu * n_cu;
         if (waves < 1) waves = 1;
         if ((size_t)waves > total) waves = (long)total;
+        /* the second pass can take `unit` macroblocks of a row per task (PCAMV_PASS2_UNIT; the dependency graph is the
+         * same on the coarser grid).  Measured at G=256: 115.1 / 114.7 / 116.9 / 122.6 ms per step for 1 / 2 / 4 / 8 --
+         * its queue traffic is not what bounds it any more; default 1.  Same buffers: the two kernels never overlap. */
+        { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : 1;
+          b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
+          b->fl2.total = (unsigned)n * (unsigned)b->fl2.n_mb;
+          unsigned qb2 = 0;
+          for (int q = 0; q < 8; q++) { b->fl2.qbase[q] = qb2; b->fl2.qcount[q] = b->fl.qcount[q] / (unsigned)F.n_mb * (unsigned)b->fl2.n_mb; qb2 += b->fl2.qcount[q]; }
+          b->fl2.dep = (int *)(b->d_flow + FLOW_CTR_WORDS + b->fl2.total); }
+        if ((size_t)waves > b->fl2.total) waves = (long)b->fl2.total;
         b->flow2_waves = (int)waves;
         if (e == hipSuccess) e = hipMemset(b->d_flow, 0, FLOW_CTR_WORDS * sizeof(unsigned));
     }
@@ -405,8 +415,8 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     }
     if (what & 8) {      /* pass 2: final MVs -> reconstruction -> loop filter, same dependency as the search */
         if (b->sched_flow) {
-            hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
-            hipLaunchKernelGGL(k_pass2_deblock_flow, dim3(b->flow2_waves), dim3(64), 0, st, dF, b->fl);
+            hipLaunchKernelGGL(k_flow_init, dim3((b->fl2.total + 255) / 256), dim3(256), 0, st, b->fl2);
+            hipLaunchKernelGGL(k_pass2_deblock_flow, dim3(b->flow2_waves), dim3(64), 0, st, dF, b->fl2);
         } else {
             for (int d = 0; d < b->n_diag; d++) {
                 int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;

@@ -352,6 +352,7 @@ struct FlowDev {
     unsigned total, spin_limit;
     unsigned qbase[8], qcount[8];
     int n_gop, n_mb, mb_w, mb_h, fused, nq;      /* nq = 8: GOP g lives in queue g & 7 (XCD affinity); nq = 1: one queue */
+    int unit;                 /* macroblocks of a row per task (second pass only; 1 by default); mb_w / n_mb above are in tasks */
 };
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FLOW_HEAD(q) (64 * (q))
@@ -442,13 +443,14 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         const unsigned long long t_s = PROF_T();
         if (MODE == 0) mbk_search(F, &L, Ap, x, y);
         else {
-#ifndef X_NOPASS2
-            mbk_pass2(F, &L, x, y);
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
-#ifndef X_NODEBLOCK
-            mbk_deblock(F, Dp, x, y);
-#endif
+            for (int k = 0; k < fl.unit; k++) {
+                const int mx = fl.unit * x + k;
+                if (mx >= F.mb_w) break;
+                if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels this one reads */
+                mbk_pass2(F, &L, mx, y);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
+                mbk_deblock(F, Dp, mx, y);
+            }
         }
         PROF_ADD(MODE ? 14 : 1, t_s);
         const unsigned long long t_p = PROF_T();
