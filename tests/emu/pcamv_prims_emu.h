@@ -106,6 +106,55 @@ static inline EvalRes prim_esa_window(const FrameDev &F, MBLocal *L, int ip, int
         }
     return r;
 }
+/* TESA row / walk / pruning (see pcamv_prims_gpu.h): the scalar statement, shaped like me.c:539-600 */
+static inline void prim_tesa_row(const FrameDev &F, MBLocal *L, int ip, int xoff, int yoff, int min_x, int my, int width, int mvp0)
+{
+    const int bw = pix_w_of(ip), bh = pix_h_of(ip), sub = ip <= PIX_8x8 ? 8 : 4;
+    for (int x = 0; x < width; x++) {
+        const uint8_t *ref = F.luma[0] + (size_t)(L->mb_y * 16 + yoff + my) * F.stride + L->mb_x * 16 + xoff + min_x + x;
+        int sad = 0, ads = 0;
+        for (int r = 0; r < bh; r++) for (int c = 0; c < bw; c++) sad += iabs(L->fenc[(yoff + r) * 16 + xoff + c] - ref[(size_t)r * F.stride + c]);
+        for (int sy = 0; sy < bh; sy += sub) for (int sx = 0; sx < bw; sx += sub) {
+            int e = 0, rr = 0;
+            for (int r = 0; r < sub; r++) for (int c = 0; c < sub; c++) { e += L->fenc[(yoff + sy + r) * 16 + xoff + sx + c]; rr += ref[(size_t)(sy + r) * F.stride + sx + c]; }
+            ads += iabs(e - rr);
+        }
+        L->ccost[x] = sad + F.cost_mv[x * 4 - mvp0];                    /* me.c:551,563: index relative to the window (sic) */
+        L->ccost[64 + x] = ads + F.cost_mv[(min_x + x) * 4 - mvp0];
+    }
+}
+static inline int prim_tesa_scan(MBLocal *L, int width, int bsad, int sad_thresh, int ycost, int ry, int *n)
+{
+    const int thresh = bsad * 17 / 16;
+    for (int x = 0; x < width; x++) {
+        if (!(L->ccost[64 + x] < thresh)) continue;
+        const int sad = L->ccost[x];
+        if (sad < (bsad * sad_thresh >> 3)) {
+            if (sad < bsad) bsad = sad;
+            *TESA_SLOT(L, *n) = TESA_PACK(sad + ycost, ry, x); (*n)++;
+        }
+    }
+    return bsad;
+}
+static inline int prim_tesa_select(MBLocal *L, int n, int limit, int bsad, int sad_thresh, int min_x, int min_y)
+{
+    if (n > limit * 2) {
+        const int thr = bsad * (sad_thresh + 8) >> 4;
+        int i = 0;
+        for (int j = 0; j < n; j++) if (TESA_SAD(*TESA_SLOT(L, j)) <= thr) { *TESA_SLOT(L, i) = *TESA_SLOT(L, j); i++; }
+        n = i;
+    }
+    if (n > limit) {
+        for (int i = 0; i < limit; i++) {
+            int bj = i, bs = TESA_SAD(*TESA_SLOT(L, i));
+            for (int j = i + 1; j < n; j++) if (TESA_SAD(*TESA_SLOT(L, j)) < bs) { bs = TESA_SAD(*TESA_SLOT(L, j)); bj = j; }
+            if (bj > i) { uint32_t t = *TESA_SLOT(L, i); *TESA_SLOT(L, i) = *TESA_SLOT(L, bj); *TESA_SLOT(L, bj) = t; }
+        }
+        n = limit;
+    }
+    for (int i = 0; i < n; i++) { const uint32_t e = *TESA_SLOT(L, i); L->cxy[i] = CAND_PACK((min_x + (int)(e & 63)) * 4, (min_y + (int)(e >> 6 & 63)) * 4); }
+    return n;
+}
 static inline int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {
     int ox = 4 * (i8 & 1), oy = 2 * (i8 & 2), s = 0;

@@ -29,7 +29,7 @@ def _params(pc, W, H, me, subme, inter, mv_range, me_range=16, tscale=256):
     return p
 
 
-GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
+GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_tesa_subme5_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
 
 
 @pytest.mark.parametrize("name", GPU_FIXTURES)
@@ -183,6 +183,11 @@ def test_open_rejects_unsupported(pc):
     p = pc.param_default(170, 144)
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)
+    p = pc.param_default(176, 144)      # --me tesa keeps its survivor list in LDS: up to me_range 16
+    pc.param_parse(p, "me", "tesa")
+    p.i_me_range = 24
+    with pytest.raises(pc.PcamvError):
+        pc.Encoder(p)
 
 
 def test_schedules_agree(pc):
@@ -262,6 +267,9 @@ SWEEP = [
     (176, 144, "esa", 16, 5, 0x30, 33, 1, 1, 1, 0, 48, 32),      # exhaustive with p4x4
     (1280, 720, "hex", 16, 5, 0x10, 26, 1, 1, 1, 0, 11, 320),    # BASELINE config 2's size and search (720p, --me hex)
     (640, 480, "esa", 16, 5, 0x10, 26, 1, 1, 1, 0, 17, 128),     # config 5's search (--me esa) on a larger picture
+    (176, 144, "tesa", 16, 4, 0x10, 30, 1, 1, 1, 0, 49, 32),     # Hadamard exhaustive search: SATD full-pel metric, ADS / SAD thresholds
+    (176, 144, "tesa", 8, 1, 0x30, 24, 1, 1, 1, 0, 50, 0),       # subme 1: the same search with the SAD metric, p4x4
+    (320, 240, "tesa", 16, 5, 0x30, 28, 1, 1, 1, 0, 51, 64),     # wider picture: windows clipped by the MV limits
 ]
 
 

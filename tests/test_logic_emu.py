@@ -10,7 +10,7 @@ import helpers
 import orc
 from emu import emu
 
-FIX = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
+FIX = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_tesa_subme5_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
 
 
 @pytest.mark.parametrize("order", [1, 2], ids=["diagonal_phases", "dataflow_fused"])

@@ -13,6 +13,7 @@
  */
 #ifndef PCAMV_COMMON_H
 #define PCAMV_COMMON_H
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/pcamv_gpu.h"
 
@@ -129,6 +130,15 @@ struct MBLocal {
     uint32_t win[(4 * 480 + 2 * 192) / 4];
     int win_x0, win_y0, win_cx0, win_cy0;     /* plane coordinates (padded-plane origin) of the window's first byte */
 };
+
+/* TESA (me.c:525-600): the positions that survive the ADS / SAD thresholds, one word each: (SAD + MV bits) << 12 |
+ * window row << 6 | window column.  Up to 32 x 33 of them (me_range <= 16); they live in LDS that is idle while a
+ * search runs: the reconstruction buffers + transform scratch (RCA / probe only), then the RCA window. */
+#define TESA_MAX_RANGE 16
+#define TESA_REGION_A ((int)((3 * 24 * 16 + 4 * 24 * 16) / 4))
+#define TESA_SLOT(L, i) ((i) < TESA_REGION_A ? (uint32_t *)((uint8_t *)(L) + offsetof(MBLocal, recb)) + (i) : (L)->win + ((i) - TESA_REGION_A))
+#define TESA_PACK(sad, ry, rx) ((uint32_t)(sad) << 12 | (uint32_t)(ry) << 6 | (uint32_t)(rx))
+#define TESA_SAD(e) ((int)((e) >> 12))
 #define NB_LEFT 1
 #define NB_TOP 2
 #define NB_TOPRIGHT 4

@@ -226,7 +226,8 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     *out = NULL;
     if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
     if (p->i_subpel_refine < 1 || p->i_subpel_refine > 5) return PCAMV_EUNSUP;   /* >=6 needs CABAC-size RDO */
-    if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_ESA) return PCAMV_EUNSUP; /* TESA keeps candidates by ADS thresholds: needs the integral image, next */
+    if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_TESA) return PCAMV_EUNSUP;
+    if (p->i_me_method == PCAMV_ME_TESA && p->i_me_range > TESA_MAX_RANGE) return PCAMV_EUNSUP;      /* the survivor list lives in LDS: 32 x 33 positions */
     if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCAMV_ENODEV;
@@ -386,13 +387,15 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         hipLaunchKernelGGL(k_chroma_pad, gc, dim3(256), 0, st, dF);
     }
     if (what & 2) {
-        int ev = -1;
+        int ev = -1, tesa = 0;
+        for (int i = 0; i < b->n; i++) tesa |= b->ctx[i]->F.me_method == PCAMV_ME_TESA;       /* the kernel instance with --me tesa compiled in */
         if (timed && !b->sched_flow) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
         for (int i = 0; i < b->n; i++) b->ctx[i]->last = b;
         if (b->sched_flow) {
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-            hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
+            if (tesa) hipLaunchKernelGGL(k_analyse_flow_tesa, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
+            else hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
         } else {
             for (int d = 0; d < b->n_diag; d++) {
@@ -400,7 +403,8 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
                 int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
                 int cnt = y_hi - y_lo + 1;
                 if (cnt <= 0) continue;
-                hipLaunchKernelGGL(k_search_diag, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                if (tesa) hipLaunchKernelGGL(k_search_diag<1>, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                else hipLaunchKernelGGL(k_search_diag<0>, dim3(cnt, G), dim3(64), 0, st, dF, d);
             }
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
             hipLaunchKernelGGL(k_rca, dim3(F.n_mb * b->slots_per_mb, G), dim3(64), 0, st, dF, b->slots_per_mb);

@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__restrict_
 }
 
 /* ------------------------------------------------------------------ analysis phases */
+template <int TESA>
 __global__ void __launch_bounds__(64) k_search_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64) k_search_diag(const FrameDev *__restrict__
     int y_lo = d - (F.mb_w - 1); y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
     int y = y_lo + (int)blockIdx.x, x = d - 2 * y;
     if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
-    mbk_search(F, &L, &A, x, y);
+    mbk_search<TESA>(F, &L, &A, x, y);
 }
 __global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int slots_per_mb)
 {
@@ -389,7 +390,7 @@ __device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot
 #endif
 /* the queue protocol, shared by the two persistent kernels; MODE 0: search -> publish -> reconstruction + RCA,
  * MODE 1: pass 2 + loop filter of the macroblock -> publish */
-template <int MODE>
+template <int MODE, int TESA>
 __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const FlowDev &fl, MBLocal &L, Analysis *Ap, DeblockLDS *Dp)
 {
     const int lane = LANE();
@@ -441,7 +442,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
         PROF_ADD(MODE ? 13 : 0, t_pop);
         const unsigned long long t_s = PROF_T();
-        if (MODE == 0) mbk_search(F, &L, Ap, x, y);
+        if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
         else {
             for (int k = 0; k < fl.unit; k++) {
                 const int mx = fl.unit * x + k;
@@ -482,7 +483,14 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const Frame
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
-    flow_loop<0>(Fs, fl, L, &A, nullptr);
+    flow_loop<0, 0>(Fs, fl, L, &A, nullptr);
+}
+/* the same kernel with --me tesa compiled in (see pcamv_logic.h: the search functions are templates on it) */
+__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa(const FrameDev *__restrict__ Fs, FlowDev fl)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    flow_loop<0, 1>(Fs, fl, L, &A, nullptr);
 }
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the
@@ -492,7 +500,7 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const
 {
     __shared__ MBLocal L;
     __shared__ DeblockLDS D;
-    flow_loop<1>(Fs, fl, L, nullptr, &D);
+    flow_loop<1, 0>(Fs, fl, L, nullptr, &D);
 }
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary

@@ -180,23 +180,35 @@ PCAMV_DEV EvalRes eval_cands(const FrameDev &F, MBLocal *L, MEState *me, const u
 {
     return prim_eval_list(F, L, enc, me->i_pixel, me->xoff, me->yoff, n, flags, me->mvp[0], me->mvp[1]);
 }
+/* The functions of the search are templates on TESA: 1 = the instance that can run --me tesa (its own kernel), 0 = the
+ * instance every other method runs, with that method's code and -- more important -- its run-time choice of the
+ * full-pel metric compiled out (the primitives are specialised on constant flags; with the flags a run-time value the
+ * other methods lost 11 %).
+ * encoder.c mbcmp_init: with --me tesa and subme > 1 the "full-pel" comparisons of the search (fpelcmp: COST_MV,
+ * COST_MV_HPEL, the half-pel rounds of refine_subpel) are SATD instead of SAD.  FPEL_LIST: flags of a list of full-pel
+ * candidates, FPEL_SAD: flags of a quarter-pel list scored with that metric. */
+#define FPEL_SATD (TESA && F.me_method == PCAMV_ME_TESA && F.subme > 1)
+#define FPEL_LIST (FPEL_SATD ? EV_SATD : EV_FPEL)
+#define FPEL_SAD (FPEL_SATD ? EV_SATD : 0)
 /* the n listed full-pel candidates folded into the running best, in list order (strict <) */
+template <int TESA>
 PCAMV_DEV int fpel_fold(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int n)
 {
-    EvalRes r = eval_cands(F, L, me, L->fenc, n, EV_FPEL);
+    EvalRes r = eval_cands(F, L, me, L->fenc, n, FPEL_LIST);
     if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx) >> 2; bmy = CAND_Y(r.idx) >> 2; return r.idx; }
     return -1;
 }
 #define FSET(c, X, Y) (L->cxy[c] = CAND_PACK((X) * 4, (Y) * 4))
 #define TRY4(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1) { \
         FSET(0, (ox) + (a0), (oy) + (a1)); FSET(1, (ox) + (b0), (oy) + (b1)); FSET(2, (ox) + (c0), (oy) + (c1)); FSET(3, (ox) + (d0), (oy) + (d1)); \
-        fpel_fold(F, L, me, bmx, bmy, bcost, 4); }
+        fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, 4); }
 #define TRY8(ox, oy, a0, a1, b0, b1, c0, c1, d0, d1, e0, e1, f0, f1, g0, g1, h0, h1) { \
         FSET(0, (ox) + (a0), (oy) + (a1)); FSET(1, (ox) + (b0), (oy) + (b1)); FSET(2, (ox) + (c0), (oy) + (c1)); FSET(3, (ox) + (d0), (oy) + (d1)); \
         FSET(4, (ox) + (e0), (oy) + (e1)); FSET(5, (ox) + (f0), (oy) + (f1)); FSET(6, (ox) + (g0), (oy) + (g1)); FSET(7, (ox) + (h0), (oy) + (h1)); \
-        fpel_fold(F, L, me, bmx, bmy, bcost, 8); }
+        fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, 8); }
 #define CHECK_MVRANGE(mx, my) ((mx) >= mv_x_min && (mx) <= mv_x_max && (my) >= mv_y_min && (my) <= mv_y_max)
 
+template <int TESA>
 PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpel_iters, int qpel_iters, int b_refine_qpel)
 {
     const int ip = me->i_pixel;
@@ -208,7 +220,7 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
         int my = clip3i(me->mvp[1], L->mv_min_spel[1], L->mv_max_spel[1]);
         if ((mx - bmx) | (my - bmy)) {
             L->cxy[0] = CAND_PACK(mx, my);
-            EvalRes r = eval_cands(F, L, me, L->fenc, 1, 0);
+            EvalRes r = eval_cands(F, L, me, L->fenc, 1, FPEL_SAD);
             if (r.cost < bcost) { bcost = r.cost; bmx = mx; bmy = my; }
         }
     }
@@ -216,7 +228,7 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
         int omx = bmx, omy = bmy;
         L->cxy[0] = CAND_PACK(omx, omy - 2); L->cxy[1] = CAND_PACK(omx, omy + 2);
         L->cxy[2] = CAND_PACK(omx - 2, omy); L->cxy[3] = CAND_PACK(omx + 2, omy);
-        EvalRes r = eval_cands(F, L, me, L->fenc, 4, 0);
+        EvalRes r = eval_cands(F, L, me, L->fenc, 4, FPEL_SAD);
         if (r.cost < bcost) { bcost = r.cost; bmx = CAND_X(r.idx); bmy = CAND_Y(r.idx); }
         if (bmx == omx && bmy == omy) break;
     }
@@ -262,6 +274,7 @@ PCAMV_DEV void refine_subpel(const FrameDev &F, MBLocal *L, MEState *me, int hpe
 
 /* the two arms of the UMH cross (me.c:331-357 CROSS): +i, -i for i = start, start+2, .. < max, first
  * along x then along y; candidates beyond the search window are skipped */
+template <int TESA>
 PCAMV_DEV void cross_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost,
                             int omx, int omy, int start, int x_max, int y_max,
                             int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
@@ -278,17 +291,18 @@ PCAMV_DEV void cross_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx
             int ok = isy ? (neg ? y >= mv_y_min : y <= mv_y_max) : (neg ? x >= mv_x_min : x <= mv_x_max);
             L->cxy[c] = ok ? CAND_PACK(x * 4, y * 4) : CAND_NONE;
         }
-        fpel_fold(F, L, me, bmx, bmy, bcost, n);
+        fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, n);
     }
 }
 
+template <int TESA>
 PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int i_me_range,
                           int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
 {
     int dir = -2;
     FOR_CAND(c, 6) L->cxy[c] = CAND_PACK((bmx + hex2_x(c + 1)) * 4, (bmy + hex2_y(c + 1)) * 4);
     {
-        EvalRes r = eval_cands(F, L, me, L->fenc, 6, EV_FPEL);
+        EvalRes r = eval_cands(F, L, me, L->fenc, 6, FPEL_LIST);
         if (r.cost < bcost) { bcost = r.cost; dir = r.idx; }
     }
     if (dir != -2) {
@@ -296,7 +310,7 @@ PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, 
         for (int i = 1; i < i_me_range / 2 && CHECK_MVRANGE(bmx, bmy); i++) {
             const int odir = mod6m1_of(dir + 1);
             FOR_CAND(c, 3) L->cxy[c] = CAND_PACK((bmx + hex2_x(odir + c)) * 4, (bmy + hex2_y(odir + c)) * 4);
-            EvalRes r = eval_cands(F, L, me, L->fenc, 3, EV_FPEL);
+            EvalRes r = eval_cands(F, L, me, L->fenc, 3, FPEL_LIST);
             dir = -2;
             if (r.cost < bcost) { bcost = r.cost; dir = odir - 1 + r.idx; }
             if (dir == -2) break;
@@ -307,6 +321,36 @@ PCAMV_DEV void hex_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, 
     TRY8(omx, omy, 0, -1, 0, 1, -1, 0, 1, 0, -1, -1, -1, 1, 1, -1, 1, 1);
 }
 
+/* Hadamard exhaustive search (me.c:525-600): the window of ESA, but a position is only remembered when its ADS and
+ * then its SAD pass thresholds relative to the best SAD so far; the list is pruned to me_range / 2 entries and those
+ * are scored with the search's comparison function (SATD above subme 1).  */
+template <int TESA>
+PCAMV_DEV void tesa_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx, int &bmy, int &bcost, int i_me_range,
+                                      int mv_x_min, int mv_x_max, int mv_y_min, int mv_y_max)
+{
+    const int ip = me->i_pixel;
+    const int min_x = imax(bmx - i_me_range, mv_x_min), min_y = imax(bmy - i_me_range, mv_y_min);
+    const int max_x = imin(bmx + i_me_range, mv_x_max), max_y = imin(bmy + i_me_range, mv_y_max);
+    const int width = (max_x - min_x + 3) & ~3;
+    if (width > 0 && max_y >= min_y) {
+        const int sad_thresh = i_me_range <= 16 ? 10 : i_me_range <= 24 ? 11 : 12;
+        int n = 0;
+        FSET(0, bmx, bmy);
+        int bsad = eval_cands(F, L, me, L->fenc, 1, EV_FPEL).cost;
+        for (int my = min_y; my <= max_y; my++) {
+            const int ycost = MVCOSTY(my * 4);
+            if (bsad <= ycost) continue;
+            bsad -= ycost;
+            prim_tesa_row(F, L, ip, me->xoff, me->yoff, min_x, my, width, me->mvp[0]);
+            bsad = prim_tesa_scan(L, width, bsad, sad_thresh, ycost, my - min_y, &n);
+            bsad += ycost;
+        }
+        n = prim_tesa_select(L, n, i_me_range / 2, bsad, sad_thresh, min_x, min_y);
+        if (n > 0) fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, n);
+    }
+}
+
+template <int TESA>
 PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc)
 {
     const int ip = me->i_pixel;
@@ -329,7 +373,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                 L->cxy[n] = CAND_PACK(clip3i(mvc[i][0], mv_x_min * 4, mv_x_max * 4), clip3i(mvc[i][1], mv_y_min * 4, mv_y_max * 4));
                 n++;
             }
-        EvalRes r = eval_cands(F, L, me, L->fenc, n, 0);
+        EvalRes r = eval_cands(F, L, me, L->fenc, n, FPEL_SAD);
         bpred_cost = r.cost; bpred_mx = CAND_X(r.idx); bpred_my = CAND_Y(r.idx);
         bmx = (bpred_mx + 2) >> 2; bmy = (bpred_my + 2) >> 2;
         FSET(0, bmx, bmy); FSET(1, 0, 0);
@@ -339,11 +383,11 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
             int n = 6;
             FSET(2, pmx, pmy - 1); FSET(3, pmx, pmy + 1); FSET(4, pmx - 1, pmy); FSET(5, pmx + 1, pmy);
             if (pmx | pmy) { FSET(6, 0, -1); FSET(7, 0, 1); FSET(8, -1, 0); FSET(9, 1, 0); n = 10; }
-            fpel_fold(F, L, me, bmx, bmy, bcost, n);
+            fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, n);
             umh_ucost1 = imin(L->ccost[0], L->ccost[1]);
             umh_diamonds_done = 1;
         } else
-            fpel_fold(F, L, me, bmx, bmy, bcost, 2);
+            fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, 2);
     } else {
         /* full-pel test: the predictor (its MV bits not charged), then the candidates, then (0,0).
          * Candidates equal to the running best are listed too: their cost cannot be smaller. */
@@ -354,7 +398,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
             if (mx | my) { FSET(n, clip3i(mx, mv_x_min, mv_x_max), clip3i(my, mv_y_min, mv_y_max)); n++; }
         }
         FSET(n, 0, 0); n++;
-        eval_cands(F, L, me, L->fenc, n, EV_FPEL);
+        eval_cands(F, L, me, L->fenc, n, FPEL_LIST);
         bcost = L->ccost[0] - (MVCOSTX(pmx * 4) + MVCOSTY(pmy * 4)); bmx = pmx; bmy = pmy;
         for (int k = 1; k < n; k++)
             if (L->ccost[k] < bcost) { bcost = L->ccost[k]; bmx = CAND_X(k) >> 2; bmy = CAND_Y(k) >> 2; }
@@ -369,7 +413,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
             if (!CHECK_MVRANGE(bmx, bmy)) break;
         } while (++i < i_me_range);
     } else if (F.me_method == PCAMV_ME_HEX) {
-        hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+        hex_search<TESA>(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
     } else if (F.me_method == PCAMV_ME_ESA) {
         /* exhaustive search (me.c:489-622).  The reference walks the window row by row, drops
          * positions whose sum-of-block-DC difference (ADS, a lower bound of the SAD) plus MV bits
@@ -384,6 +428,8 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
             EvalRes r = prim_esa_window(F, L, ip, me->xoff, me->yoff, min_x, min_y, width, max_y - min_y + 1, me->mvp[0], me->mvp[1]);
             if (r.cost < bcost) { bcost = r.cost; bmx = min_x + r.idx % width; bmy = min_y + r.idx / width; }
         }
+    } else if (TESA && F.me_method == PCAMV_ME_TESA) {
+        tesa_search<TESA>(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
 #define SAD_THRESH(v) (bcost < ((v) >> size_shift_of(ip)))
@@ -403,7 +449,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                 if (bcost == ucost1 && SAD_THRESH(500)) { done = 1; do_hex = 0; }
                 else if (bcost == ucost2) {
                     int range = (i_me_range >> 1) | 1;
-                    cross_search(F, L, me, bmx, bmy, bcost, omx, omy, 3, range, range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+                    cross_search<TESA>(F, L, me, bmx, bmy, bcost, omx, omy, 3, range, range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
                     TRY8(omx, omy, -1, -2, 1, -2, -2, -1, 2, -1, -2, 1, 2, 1, -1, 2, 1, 2);
                     if (bcost == ucost2) { done = 1; do_hex = 0; }
                     cross_start = range + 2;
@@ -424,7 +470,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                     mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
                     i_me_range = i_me_range * range_mul_of(mvd_ctx, sad_ctx) / 4;
                 }
-                cross_search(F, L, me, bmx, bmy, bcost, omx, omy, cross_start, i_me_range, i_me_range / 2, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+                cross_search<TESA>(F, L, me, bmx, bmy, bcost, omx, omy, cross_start, i_me_range, i_me_range / 2, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
                 TRY4(omx, omy, -2, -2, -2, 2, 2, -2, 2, 2);
                 /* 16-point hexagons at radii 4, 8, .. around the (fixed) cross result, me.c:404-457 */
                 omx = bmx; omy = bmy;
@@ -436,12 +482,12 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
                         int mx = omx + hex4_x(j) * i, my = omy + hex4_y(j) * i;
                         L->cxy[c] = CHECK_MVRANGE(mx, my) ? CAND_PACK(mx * 4, my * 4) : CAND_NONE;
                     }
-                    fpel_fold(F, L, me, bmx, bmy, bcost, n);
+                    fpel_fold<TESA>(F, L, me, bmx, bmy, bcost, n);
                 }
                 if (!(bmy <= mv_y_max)) do_hex = 0;
             }
         }
-        if (do_hex) hex_search(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
+        if (do_hex) hex_search<TESA>(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
 #undef SAD_THRESH
     }
 
@@ -449,13 +495,14 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
     else { me->mv[0] = bmx * 4; me->mv[1] = bmy * 4; me->cost = bcost; }
     me->cost_mv = MVCOSTX(me->mv[0]) + MVCOSTY(me->mv[1]);
     if (bmx == pmx && bmy == pmy && F.subme < 3) me->cost += me->cost_mv;
-    if (F.subme >= 2) refine_subpel(F, L, me, subpel_iter_of(F.subme, 2), subpel_iter_of(F.subme, 3), 0);
+    if (F.subme >= 2) refine_subpel<TESA>(F, L, me, subpel_iter_of(F.subme, 2), subpel_iter_of(F.subme, 3), 0);
     else if (me->mv[1] > L->mv_max_spel[1]) me->mv[1] = L->mv_max_spel[1];
 }
 
+template <int TESA>
 PCAMV_DEV void me_refine_qpel(const FrameDev &F, MBLocal *L, MEState *me)
 {
-    refine_subpel(F, L, me, subpel_iter_of(F.subme, 0), subpel_iter_of(F.subme, 1), 1);
+    refine_subpel<TESA>(F, L, me, subpel_iter_of(F.subme, 0), subpel_iter_of(F.subme, 1), 1);
 }
 
 /* ---------------------------------------------------------------- macroblock (re-)encode */
@@ -542,6 +589,7 @@ PCAMV_DEV void update_cache(MBLocal *L, Analysis *a)
     }
 }
 
+template <int TESA>
 PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_try_pskip)
 {
     MEState me;
@@ -549,7 +597,7 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
     predict_mv_16x16(L, 0, me.mvp);
     for (int i = 0; i < 9; i++) { L->mvc16[i][0] = 0; L->mvc16[i][1] = 0; }
     int i_mvc = predict_mv_ref16x16(F, L, L->mvc16);
-    me_search(F, L, &me, L->mvc16, i_mvc);
+    me_search<TESA>(F, L, &me, L->mvc16, i_mvc);
     if (b_try_pskip && me.cost - me.cost_mv < 300 * F.lambda &&
         iabs(me.mv[0] - L->pskip_mv[0]) + iabs(me.mv[1] - L->pskip_mv[1]) <= 1 && probe_pskip(F, L)) {
         L->i_type = PCAMV_P_SKIP;
@@ -564,6 +612,7 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
     L->i_type = PCAMV_P_L0;
     return 0;
 }
+template <int TESA>
 PCAMV_DEV void analyse_p8x8(const FrameDev &F, MBLocal *L, Analysis *a)
 {
     int i_mvc = 1;
@@ -574,7 +623,7 @@ PCAMV_DEV void analyse_p8x8(const FrameDev &F, MBLocal *L, Analysis *a)
         int x8 = i % 2, y8 = i / 2;
         me_setup(me, PIX_8x8, 8 * x8, 8 * y8);
         predict_mv(L, 4 * i, 2, me->mvp);
-        me_search(F, L, me, a->mvc, i_mvc);
+        me_search<TESA>(F, L, me, a->mvc, i_mvc);
         cache_mv_set(L, 2 * x8, 2 * y8, 2, 2, me->mv[0], me->mv[1]);
         a->mvc[i_mvc][0] = me->mv[0]; a->mvc[i_mvc][1] = me->mv[1]; i_mvc++;
         me->cost += F.lambda * 1;
@@ -582,6 +631,7 @@ PCAMV_DEV void analyse_p8x8(const FrameDev &F, MBLocal *L, Analysis *a)
     a->cost8x8 = a->me8x8[0].cost + a->me8x8[1].cost + a->me8x8[2].cost + a->me8x8[3].cost;
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
 }
+template <int TESA>
 PCAMV_DEV void analyse_p16x8(const FrameDev &F, MBLocal *L, Analysis *a)
 {
     L->i_partition = PCAMV_D_16x8;
@@ -593,12 +643,13 @@ PCAMV_DEV void analyse_p16x8(const FrameDev &F, MBLocal *L, Analysis *a)
         mvc[2][0] = a->mvc[2 * i + 2][0]; mvc[2][1] = a->mvc[2 * i + 2][1];
         cache_ref_set(L, 0, 2 * i, 4, 2, 0);
         predict_mv(L, 8 * i, 4, me.mvp);
-        me_search(F, L, &me, mvc, 3);
+        me_search<TESA>(F, L, &me, mvc, 3);
         a->me16x8[i] = me;
         cache_mv_set(L, 0, 2 * i, 4, 2, me.mv[0], me.mv[1]);
     }
     a->cost16x8 = a->me16x8[0].cost + a->me16x8[1].cost;
 }
+template <int TESA>
 PCAMV_DEV void analyse_p8x16(const FrameDev &F, MBLocal *L, Analysis *a)
 {
     L->i_partition = PCAMV_D_8x16;
@@ -610,12 +661,13 @@ PCAMV_DEV void analyse_p8x16(const FrameDev &F, MBLocal *L, Analysis *a)
         mvc[2][0] = a->mvc[i + 3][0]; mvc[2][1] = a->mvc[i + 3][1];
         cache_ref_set(L, 2 * i, 0, 2, 4, 0);
         predict_mv(L, 4 * i, 2, me.mvp);
-        me_search(F, L, &me, mvc, 3);
+        me_search<TESA>(F, L, &me, mvc, 3);
         a->me8x16[i] = me;
         cache_mv_set(L, 2 * i, 0, 2, 4, me.mv[0], me.mv[1]);
     }
     a->cost8x16 = a->me8x16[0].cost + a->me8x16[1].cost;
 }
+template <int TESA>
 PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8, int pixel)
 {
     L->i_partition = PCAMV_D_8x8;
@@ -628,7 +680,7 @@ PCAMV_DEV void analyse_sub8x8(const FrameDev &F, MBLocal *L, Analysis *a, int i8
         int mvc[1][2];
         const MEState *cand = pixel == PIX_4x4 ? &a->me8x8[i8] : &a->me4x4[i8][0];
         mvc[0][0] = cand->mv[0]; mvc[0][1] = cand->mv[1];
-        me_search(F, L, me, mvc, k == 0);
+        me_search<TESA>(F, L, me, mvc, k == 0);
         cache_mv_set(L, blk_x_of(idx), blk_y_of(idx), pixel == PIX_8x4 ? 2 : 1, pixel == PIX_4x8 ? 2 : 1, me->mv[0], me->mv[1]);
         cost += me->cost;
     }
@@ -767,6 +819,7 @@ PCAMV_DEV int carrier_of_block(int i_type, int i_partition, const uint8_t *sub, 
 /* Analyse one macroblock (motion search, partition decision, early skip) and publish its final
  * motion to the frame arrays its right/lower neighbours read.  Writes the record without the
  * RCA fields; the search-time mvp of every carrier slot goes to mvp_aux for phase B. */
+template <int TESA>
 PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
 {
     int b_skip = 0, b_try_pskip = 0, i_cost;
@@ -780,11 +833,11 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
             b_skip = probe_pskip(F, L);
     }
     if (b_skip) { L->i_type = PCAMV_P_SKIP; L->i_partition = PCAMV_D_16x16; }
-    else if (!analyse_p16x16(F, L, a, b_try_pskip)) {
+    else if (!analyse_p16x16<TESA>(F, L, a, b_try_pskip)) {
         PROF_ADD(6, t_a);
         int i_type = PCAMV_P_L0, i_partition = PCAMV_D_16x16;
         const unsigned long long t_b = PROF_T();
-        if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8(F, L, a);
+        if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8<TESA>(F, L, a);
         PROF_ADD(7, t_b);
         const unsigned long long t_c = PROF_T();
         i_cost = a->me16x16.cost;
@@ -792,13 +845,13 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
             if (flags & PCAMV_ANALYSE_PSUB8x8) {
                 i_type = PCAMV_P_8x8; i_partition = PCAMV_D_8x8; i_cost = a->cost8x8;
                 for (int i = 0; i < 4; i++) {
-                    analyse_sub8x8(F, L, a, i, PIX_4x4);
+                    analyse_sub8x8<TESA>(F, L, a, i, PIX_4x4);
                     if (a->cost4x4[i] < a->me8x8[i].cost) {
                         int c8 = a->cost4x4[i];
                         L->sub_part[i] = PCAMV_D_L0_4x4;
-                        analyse_sub8x8(F, L, a, i, PIX_8x4);
+                        analyse_sub8x8<TESA>(F, L, a, i, PIX_8x4);
                         if (a->cost8x4[i] < c8) { c8 = a->cost8x4[i]; L->sub_part[i] = PCAMV_D_L0_8x4; }
-                        analyse_sub8x8(F, L, a, i, PIX_4x8);
+                        analyse_sub8x8<TESA>(F, L, a, i, PIX_4x8);
                         if (a->cost4x8[i] < c8) { c8 = a->cost4x8[i]; L->sub_part[i] = PCAMV_D_L0_4x8; }
                         i_cost += c8 - a->me8x8[i].cost;
                     }
@@ -808,24 +861,24 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
             }
         }
         if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost + a->me8x8[1].cost_mv + a->me8x8[2].cost_mv) {
-            analyse_p16x8(F, L, a);
+            analyse_p16x8<TESA>(F, L, a);
             if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x8; }
-            analyse_p8x16(F, L, a);
+            analyse_p8x16<TESA>(F, L, a);
             if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
         }
         L->i_partition = i_partition;
         PROF_ADD(8, t_c);
         const unsigned long long t_d = PROF_T();
-        if (i_partition == PCAMV_D_16x16) me_refine_qpel(F, L, &a->me16x16);
-        else if (i_partition == PCAMV_D_16x8) { me_refine_qpel(F, L, &a->me16x8[0]); me_refine_qpel(F, L, &a->me16x8[1]); }
-        else if (i_partition == PCAMV_D_8x16) { me_refine_qpel(F, L, &a->me8x16[0]); me_refine_qpel(F, L, &a->me8x16[1]); }
+        if (i_partition == PCAMV_D_16x16) me_refine_qpel<TESA>(F, L, &a->me16x16);
+        else if (i_partition == PCAMV_D_16x8) { me_refine_qpel<TESA>(F, L, &a->me16x8[0]); me_refine_qpel<TESA>(F, L, &a->me16x8[1]); }
+        else if (i_partition == PCAMV_D_8x16) { me_refine_qpel<TESA>(F, L, &a->me8x16[0]); me_refine_qpel<TESA>(F, L, &a->me8x16[1]); }
         else
             for (int i = 0; i < 4; i++)
                 switch (L->sub_part[i]) {
-                case PCAMV_D_L0_8x8: me_refine_qpel(F, L, &a->me8x8[i]); break;
-                case PCAMV_D_L0_8x4: me_refine_qpel(F, L, &a->me8x4[i][0]); me_refine_qpel(F, L, &a->me8x4[i][1]); break;
-                case PCAMV_D_L0_4x8: me_refine_qpel(F, L, &a->me4x8[i][0]); me_refine_qpel(F, L, &a->me4x8[i][1]); break;
-                default: for (int k = 0; k < 4; k++) me_refine_qpel(F, L, &a->me4x4[i][k]); break;
+                case PCAMV_D_L0_8x8: me_refine_qpel<TESA>(F, L, &a->me8x8[i]); break;
+                case PCAMV_D_L0_8x4: me_refine_qpel<TESA>(F, L, &a->me8x4[i][0]); me_refine_qpel<TESA>(F, L, &a->me8x4[i][1]); break;
+                case PCAMV_D_L0_4x8: me_refine_qpel<TESA>(F, L, &a->me4x8[i][0]); me_refine_qpel<TESA>(F, L, &a->me4x8[i][1]); break;
+                default: for (int k = 0; k < 4; k++) me_refine_qpel<TESA>(F, L, &a->me4x4[i][k]); break;
                 }
         L->i_type = i_type;
         PROF_ADD(9, t_d);

@@ -20,12 +20,13 @@
 #define PCAMV_LANE0 (LANE() == 0)
 #endif
 
+template <int TESA>
 PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
 {
     const unsigned long long t_l = PROF_T();
     mb_load(F, L, mb_x, mb_y);
     PROF_ADD(11, t_l);
-    analyse_mb_search(F, L, a);
+    analyse_mb_search<TESA>(F, L, a);
     const unsigned long long t_w = PROF_T();
     const int xy = L->mb_xy;
     int *slots = L->slots;

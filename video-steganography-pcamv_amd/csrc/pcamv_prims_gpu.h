@@ -418,6 +418,105 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
     return res;
 }
 
+/* TESA, one row of the window (me.c:539-566): for every full-pel position x in [min_x, min_x + width), y = my:
+ * SAD + MV bits of x - min_x (sic) -> L->ccost[x], ADS + x MV bits -> L->ccost[64 + x].  ADS (pixel.c:515-559) = sum over the
+ * partition's 8x8 (4x4 below 8x8) sub-blocks of |sum(fenc sub-block) - sum(reference sub-block)|; the reference gets
+ * the sums from an integral image, here they come from the pixels the SAD reads anyway.  lane = x (width <= 64). */
+__device__ __forceinline__ void prim_tesa_row(const FrameDev &F, MBLocal *L, int ip_, int xoff_, int yoff_, int min_x_, int my_, int width_, int mvp0_)
+{
+    const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), min_x = rfl(min_x_), my = rfl(my_), width = rfl(width_), mvp0 = rfl(mvp0_);
+    const int lane = LANE();
+    const int bw = pix_w_of(ip), bh = pix_h_of(ip), sub = ip <= PIX_8x8 ? 8 : 4;
+    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    const gp8 lb = (gp8)F.luma_base;
+    const uint32_t stride = (uint32_t)F.stride;
+    PCAMV_WAVE_SYNC();
+    if (lane < width) {
+        const uint32_t base = (uint32_t)(L->mb_y * 16 + yoff + my + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + xoff + min_x + lane + PCAMV_PAD);
+        int sad = 0, rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, es0 = 0, es1 = 0, es2 = 0, es3 = 0;
+        for (int r = 0; r < bh; r++)
+            for (int j = 0; j < bw; j += 4) {
+                const uint32_t ref = gld4(lb, base + (uint32_t)r * stride + (uint32_t)j), e = lds4(L->fenc + (yoff + r) * 16 + xoff + j);
+                sad = (int)__builtin_amdgcn_sad_u8(ref, e, (uint32_t)sad);
+                const int rsum = (int)__builtin_amdgcn_sad_u8(ref, 0u, 0u), esum = (int)__builtin_amdgcn_sad_u8(e, 0u, 0u);
+                const int k = (r >= sub ? 2 : 0) + (j >= sub ? 1 : 0);
+                rs0 += k == 0 ? rsum : 0; rs1 += k == 1 ? rsum : 0; rs2 += k == 2 ? rsum : 0; rs3 += k == 3 ? rsum : 0;
+                es0 += k == 0 ? esum : 0; es1 += k == 1 ? esum : 0; es2 += k == 2 ? esum : 0; es3 += k == 3 ? esum : 0;
+            }
+        /* sub-blocks the partition does not have keep 0 - 0 */
+        const int ads = iabs(es0 - rs0) + iabs(es1 - rs1) + iabs(es2 - rs2) + iabs(es3 - rs3);
+        /* me.c:551,563: the SAD of a position is charged cost_fpel_mvx[x] with x RELATIVE to the window (the ADS gets the
+         * position's real MV bits, cost_fpel_mvx + min_x) -- the reference's arithmetic, kept */
+        L->ccost[lane] = sad + (int)cost_tab[(uint32_t)(lane * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
+        L->ccost[64 + lane] = ads + (int)cost_tab[(uint32_t)((min_x + lane) * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
+    }
+    PCAMV_WAVE_SYNC();
+}
+/* TESA, the reference's walk over that row (me.c:549-566) for all positions at once: a position is looked at when its
+ * ADS is below bsad * 17 / 16 (bsad as at the start of the row); walking them in order, one is kept when its SAD is
+ * below bsad * sad_thresh >> 3 and lowers bsad when below it.  bsad before position x is therefore
+ * min(bsad at row start, smallest looked-at SAD left of x): an exclusive prefix minimum.  Kept positions are appended
+ * to the list in order.  Returns the row's final bsad. */
+__device__ __forceinline__ int prim_tesa_scan(MBLocal *L, int width_, int bsad_, int sad_thresh_, int ycost_, int ry_, int *n_)
+{
+    const int width = rfl(width_), bsad0 = rfl(bsad_), sad_thresh = rfl(sad_thresh_), ycost = rfl(ycost_), ry = rfl(ry_), n = rfl(*n_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    const bool look = lane < width && L->ccost[64 + lane] < bsad0 * 17 / 16;
+    const int sad = lane < width ? L->ccost[lane] : 0;
+    int incl = look ? sad : 0x7fffffff;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = imin(incl, o); }
+    int before = __shfl_up(incl, 1);
+    before = lane == 0 ? bsad0 : imin(bsad0, before);
+    const bool keep = look && sad < (before * sad_thresh >> 3);
+    const unsigned long long m = __ballot(keep);
+    if (keep) *TESA_SLOT(L, n + __popcll(m & ((1ull << lane) - 1))) = TESA_PACK(sad + ycost, ry, lane);
+    *n_ = n + __popcll(m);
+    const int bsad = imin(bsad0, rfl(__shfl(incl, 63)));
+    PCAMV_WAVE_SYNC();
+    return bsad;
+}
+/* TESA, pruning of the list (me.c:567-600): above 2 * limit entries keep those with SAD <= bsad * (sad_thresh + 8) >> 4
+ * (stable); above limit entries a partial selection sort brings the `limit` smallest to the front (first smallest
+ * wins, found entry swapped with the one in its place -- the swaps decide later ties, so they are made as written).
+ * The survivors become the candidate list L->cxy.  Returns their number. */
+__device__ __forceinline__ int prim_tesa_select(MBLocal *L, int n_, int limit_, int bsad_, int sad_thresh_, int min_x_, int min_y_)
+{
+    int n = rfl(n_);
+    const int limit = rfl(limit_), min_x = rfl(min_x_), min_y = rfl(min_y_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    if (n > limit * 2) {
+        const int thr = rfl(bsad_) * (rfl(sad_thresh_) + 8) >> 4;
+        int kept = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) {            /* in place: an entry only ever moves towards the front */
+            const uint32_t e = b0 + lane < n ? *TESA_SLOT(L, b0 + lane) : 0u;
+            const bool keep = b0 + lane < n && TESA_SAD(e) <= thr;
+            const unsigned long long m = __ballot(keep);
+            PCAMV_WAVE_SYNC();
+            if (keep) *TESA_SLOT(L, kept + __popcll(m & ((1ull << lane) - 1))) = e;
+            kept += __popcll(m);
+            PCAMV_WAVE_SYNC();
+        }
+        n = kept;
+    }
+    if (n > limit) {
+        for (int i = 0; i < limit; i++) {
+            int best = 0x7fffffff;                      /* SAD << 11 | index: smallest SAD, first index (n <= 1056) */
+            for (int j = i + lane; j < n; j += 64) best = imin(best, (TESA_SAD(*TESA_SLOT(L, j)) << 11) | j);
+            best = wave_min_i32(best);
+            const int bj = best & 2047;
+            if (lane == 0 && bj > i) { const uint32_t t = *TESA_SLOT(L, i); *TESA_SLOT(L, i) = *TESA_SLOT(L, bj); *TESA_SLOT(L, bj) = t; }
+            PCAMV_WAVE_SYNC();
+        }
+        n = limit;
+    }
+    if (lane < n) { const uint32_t e = *TESA_SLOT(L, lane); L->cxy[lane] = CAND_PACK((min_x + (int)(e & 63)) * 4, (min_y + (int)(e >> 6 & 63)) * 4); }
+    PCAMV_WAVE_SYNC();
+    return n;
+}
+
 /* analyse.c:1535-1567: chroma cost of one 8x8 split below 8x8; mv4[k] = MV of luma 4x4 k (raster in the 8x8) */
 __device__ __forceinline__ int prim_chroma4x4_cost(const FrameDev &F, MBLocal *L, int i8, const int mv4x[4], const int mv4y[4], int satd)
 {

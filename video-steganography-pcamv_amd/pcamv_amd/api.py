@@ -168,7 +168,7 @@ class Encoder:
         rc = self.lib.pcamv_gpu_open(C.byref(params), device, C.byref(ctx))
         if rc:
             names = {-1: "invalid parameter", -2: "no HIP device (there is no CPU fallback)", -3: "out of memory",
-                     -4: "HIP error", -5: "unsupported (subme>=6 / esa / tesa are not on the GPU path yet)"}
+                     -4: "HIP error", -5: "unsupported (subme >= 6, tesa with me_range > 16, picture not a multiple of 16, ... are not on the GPU path)"}
             raise PcamvError(f"pcamv_gpu_open failed: {names.get(rc, rc)}")
         self.ctx = ctx
 
