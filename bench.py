@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--emrate", type=float, default=0.5)
     ap.add_argument("--open-loop", action="store_true", help="pass 1 only: no pass 2 / loop filter, the reference is the previous source frame")
     ap.add_argument("--closed-loop", action="store_true", help="(default) pass 2 + loop filter on the GPU, the deblocked reconstruction is the next reference")
+    ap.add_argument("--host-io-steps", type=int, default=3, help="extra untimed-for-`value` steps that also move each frame's source pictures host->device (pinned) and its records + embedding vectors device->host, reported as `pcie_inclusive` (0 = skip; rank 0, N=1 only)")
     ap.add_argument("--cpu-frames", type=int, default=6, help="P frames timed for the CPU baseline (0 = skip)")
     args = ap.parse_args()
     args.closed_loop = not args.open_loop
@@ -131,6 +132,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the same steps with the boundary's host traffic inside the timed region: source frame up (pinned, async on the step's
+    # stream), per-macroblock records + embedding vectors down (the C ABI's blocking fetch); nothing is overlapped
+    hio = None
+    if rank == 0 and world == 1 and args.host_io_steps > 0:
+        hsrc = [[pl.cpu().pin_memory() for pl in fr] for fr in dframes]
+        dstage = [[torch.empty_like(pl) for pl in dframes[0]] for _ in encs]
+        down = 0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(args.host_io_steps):
+            tt = args.warmup + args.steps + t
+            with torch.cuda.stream(stream):
+                for g in range(len(encs)):
+                    for dst, src in zip(dstage[g], hsrc[(tt + g + 1) % nfr]):
+                        dst.copy_(src, non_blocking=True)
+            for g, enc in enumerate(encs):
+                if args.closed_loop:
+                    enc.set_ref_device(recon[g][0], recon[g][1], recon[g][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+                else:
+                    a = dframes[(tt + g) % nfr]
+                    enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+                enc.set_fenc_device(dstage[g][0].data_ptr(), dstage[g][1].data_ptr(), dstage[g][2].data_ptr())
+            batch.step(args.qp, args.emrate, stream.cuda_stream)
+            for enc in encs:
+                m_h, e_h = enc.fetch_results(want_embed=True)
+                down += m_h.nbytes + sum(np.asarray(v).nbytes for v in e_h.values() if hasattr(v, "nbytes"))
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        up = sum(pl.numel() for pl in hsrc[0]) * len(encs) * args.host_io_steps
+        hio = {"value": args.gops * n_mb * args.host_io_steps / dth, "unit": "MB/s", "ms_per_step": dth / args.host_io_steps * 1e3,
+               "h2d_bytes_per_frame": up / (len(encs) * args.host_io_steps), "d2h_bytes_per_frame": down / (len(encs) * args.host_io_steps),
+               "note": "source frames host->device from pinned memory + records and embedding vectors device->host through the C ABI, serialised with the compute (no overlap)"}
     if prof is not None:
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 0)
         nmb = args.gops * n_mb * args.steps
@@ -198,6 +231,8 @@ def main():
                      "issue_bound": issue},
     }
 
+    if hio is not None:
+        out["pcie_inclusive"] = hio
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
