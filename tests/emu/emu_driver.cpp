@@ -41,7 +41,7 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     Analysis *a = (Analysis *)malloc(sizeof(Analysis));
     if (diag_order == 2) {  /* dataflow schedule: search, then RCA + reconstruction of the same macroblock, in a dependency-legal order */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<1>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x); } }
+            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<1>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1); } }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
         return 0;
     }

@@ -472,7 +472,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         if (MODE == 0 && fl.fused) {
             if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
             have_ticket = true;
-            mbk_rca_encode(F, &L, Ap, xy);
+            mbk_rca_encode(F, &L, Ap, xy, 1);
         }
         PROF_ADD(3, t_r);
         if (MODE == 0) PROF_ADD(4, t_pop);

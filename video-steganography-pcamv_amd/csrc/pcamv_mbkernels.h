@@ -103,11 +103,21 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
  * every carrier's replacement-MV cost.  The reconstruction of the macroblock as decided is also the
  * first re-encode of every carrier's RCA step, so it is made once (L->recb0); rca_mv_cost leaves the
  * decided MVs and the cache as it found them, so one rebuild of the analysis serves all carriers. */
-PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+/* fused = this wave has just searched this macroblock (dataflow schedule): MBLocal and Analysis still hold what
+ * analysis_from_record would rebuild from the record (neighbour cache, limits, source pixels, decided MVs in the cache,
+ * the carriers' search states), so only the fields that call resets are reset */
+PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0)
 {
     const unsigned long long t_e = PROF_T();
-    const int n = analysis_from_record(F, L, a, xy, L->slots);
-    update_cache(L, a);
+    int n;
+    if (fused) {
+        L->b_skip_mc = 0;
+        n = carrier_slots(L->i_type, L->i_partition, L->sub_part, L->i_type != PCAMV_P_SKIP, L->slots);
+        for (int k = 0; k < n; k++) { MEState *me = slot_me(L, a, L->slots[k]); me->cost = me->cost_mv = me->cost_rec = 0; }
+    } else {
+        n = analysis_from_record(F, L, a, xy, L->slots);
+        update_cache(L, a);
+    }
     mb_encode(F, L);
     prim_store_rec(F, L);
     PROF_ADD(10, t_e);
@@ -138,9 +148,9 @@ PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, i
         }
     }
 }
-PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
+PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0)
 {
-    mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy));
+    mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy, fused));
 }
 
 /* pass 2 of one macroblock (analyse.c:2870-3107 + x264_macroblock_encode, semantics of DESIGN.md 5b): the
