@@ -60,8 +60,8 @@ enum { PCAMV_D_L0_4x4 = 0, PCAMV_D_L0_8x4 = 1, PCAMV_D_L0_4x8 = 2, PCAMV_D_L0_8x
  * names and its post-x264_validate_parameters meaning (encoder.c:342-613). */
 typedef struct pcamv_params_t {
     int32_t i_width, i_height;        /* luma size, multiples of 16                              */
-    int32_t i_me_method;              /* analyse.i_me_method  (PCAMV_ME_*)                       */
-    int32_t i_me_range;               /* analyse.i_me_range   (default 16, common.c:121)         */
+    int32_t i_me_method;              /* analyse.i_me_method  (PCAMV_ME_*, all five)             */
+    int32_t i_me_range;               /* analyse.i_me_range   (default 16, common.c:121); <= 16 with PCAMV_ME_TESA */
     int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..5 here (>=6 needs RDO: next)*/
     int32_t i_mv_range;               /* analyse.i_mv_range after level lookup, encoder.c:558    */
     int32_t b_chroma_me;              /* analyse.b_chroma_me  (default 1)                        */
