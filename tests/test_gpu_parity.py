@@ -218,6 +218,56 @@ def test_schedules_agree(pc):
         assert np.array_equal(a[2][k], b[2][k]), k
 
 
+def test_closed_loop_schedules_agree_at_scale(pc):
+    """1080p, 32 closed GOPs (four per XCD queue), two closed-loop steps: the dataflow kernels (neighbour hand-off by
+    write-through stores + agent-scope loads, work stealing between the queues) against the per-anti-diagonal
+    launches, whose ordering comes from kernel boundaries -- records, flip maps and deblocked pictures of every GOP.
+    A size-independent property: the two schedules are the same computation."""
+    import os
+    import torch
+    from pcamv_amd.synth import make_clip
+    W, H, G, qp = 1920, 1088, 32, 26
+    clip = make_clip(W, H, 4, seed=13)
+    dev = torch.device("cuda", 0)
+    d = [[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip]
+    p = _params(pc, W, H, pc.ME_NAMES["umh"], 5, 0x10, pc.level_mv_range(W, H))
+    out = {}
+    for sched in ("diag", "flow"):
+        if sched == "diag":
+            os.environ["PCAMV_SCHED"] = "diag"
+        try:
+            encs = [pc.Encoder(p) for _ in range(G)]
+            batch = pc.Batch(encs)
+        finally:
+            os.environ.pop("PCAMV_SCHED", None)
+        batch.set_closed_loop(True)
+        res = []
+        for t in (0, 1):
+            for g, enc in enumerate(encs):
+                if t == 0:
+                    a = d[g % 3]
+                    enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+                else:
+                    r = enc.recon_device()
+                    enc.set_ref_device(r[0], r[1], r[2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+                b = d[(g + t) % 3 + 1]
+                enc.set_fenc_device(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
+            batch.step(qp, 0.5, 0)
+            for enc in encs:
+                mbs, emb = enc.fetch_results(want_embed=True)
+                res.append((mbs, emb["flip"].copy(), [x.copy() for x in enc.fetch_recon()]))
+        out[sched] = res
+        batch.close()
+        for enc in encs:
+            enc.close()
+    for i, (a, b) in enumerate(zip(out["diag"], out["flow"])):
+        for f in a[0].dtype.names:
+            assert np.array_equal(a[0][f], b[0][f]), f"step {i // G} GOP {i % G}: {f}"
+        assert np.array_equal(a[1], b[1]), f"step {i // G} GOP {i % G}: flips"
+        for x, y, nm in zip(a[2], b[2], "yuv"):
+            assert np.array_equal(x, y), f"step {i // G} GOP {i % G}: deblocked {nm}"
+
+
 def test_1080p_batch_step_matches_oracle(pc):
     """BASELINE's size through the batch API (device-resident planes, several closed GOPs advanced by one
     dataflow launch): every GOP's record, embedding vectors and extracted payload against the oracle."""
