@@ -169,7 +169,7 @@ def main():
         nmb = args.gops * n_mb * args.steps
         names = ["pop+wait", "search", "publish", "reconstruct+RCA", "whole iteration", "-", "16x16 (+skip probe)", "8x8", "sub8x8 + 16x8 + 8x16",
                  "final qpel refine", "reconstruction", "neighbour load", "record store",
-                 "pass 2: pop+wait", "pass 2: reconstruct + filter", "pass 2: publish"]
+                 "pop: ticket (or pass 2: pop+wait)", "pop: queue entry wait (or pass 2: work)", "pop: descriptor load (or pass 2: publish)"]
         print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
     # dominant kernel: average duration of one launch, HIP events on its own stream
     dom = batch.dominant_kernel()

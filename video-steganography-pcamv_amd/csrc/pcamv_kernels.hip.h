@@ -410,6 +410,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         if (!have_ticket && lane == 0) idx = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
         have_ticket = false;
         idx = flow_bcast(idx);
+        if (MODE == 0) PROF_ADD(13, t_pop);
+        const unsigned long long t_item = PROF_T();
         if (idx >= fl.qcount[home]) {                      /* this queue is handed out: next one, or done */
             if (++tried >= fl.nq) break;
             home = (home + 1) & (fl.nq - 1);
@@ -429,6 +431,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
             if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
         }
         if (!item) { if (lane == 0) __hip_atomic_store(&fl.ctr[FLOW_ERR], 1u, RLX_AGENT); break; }
+        if (MODE == 0) PROF_ADD(14, t_item);
+        const unsigned long long t_f = PROF_T();
 #ifdef PCAMV_FLOW_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         /* drop this CU's stale L1 lines of the neighbours' motion */
 #else
@@ -440,6 +444,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         const int g = (int)((item - 1u) >> 16), xy = (int)((item - 1u) & 0xffffu);
         const FrameDev F = Fs[g];
         const int y = xy / fl.mb_w, x = xy - y * fl.mb_w;
+        if (MODE == 0) PROF_ADD(15, t_f);
         PROF_ADD(MODE ? 13 : 0, t_pop);
         const unsigned long long t_s = PROF_T();
         if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
