@@ -108,12 +108,15 @@ PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
     return i;
 }
 
-PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
+/* lite: only what the reconstruction of a macroblock with known MVs needs (position, MV limits, source pixels) --
+ * no neighbour types / motion, no skip prediction (second pass of a macroblock that is not P_SKIP) */
+PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int lite = 0)
 {
     L->mb_x = mb_x; L->mb_y = mb_y; L->mb_xy = mb_y * F.mb_w + mb_x;
     L->b_skip_mc = 0;
     L->neighbour = 0;
     L->type_left = L->type_top = L->type_topleft = L->type_topright = -1;
+    if (!lite) {
     int top = L->mb_xy - F.mb_w;
     if (mb_y > 0) { L->neighbour |= NB_TOP; L->type_top = NB_LD8(&F.mb_type[top]); }
     if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = NB_LD8(&F.mb_type[L->mb_xy - 1]); }
@@ -138,6 +141,7 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
     int pm[2];
     predict_mv_pskip(L, pm);
     L->pskip_mv[0] = (int16_t)pm[0]; L->pskip_mv[1] = (int16_t)pm[1];
+    }
 
     int fmv = 4 * F.mv_range;
     L->mv_min[0] = 4 * (-16 * mb_x - 24);

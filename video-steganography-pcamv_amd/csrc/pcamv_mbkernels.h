@@ -160,9 +160,9 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
  * dependency as the search. */
 PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
 {
-    mb_load(F, L, mb_x, mb_y);
-    const int xy = L->mb_xy;
+    const int xy = mb_y * F.mb_w + mb_x;
     const pcamv_mb_t *r = &F.rec_mb[xy];
+    mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
     L->i_type = r->i_type; L->i_partition = r->i_partition;
     for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
     cache_ref_set(L, 0, 0, 4, 4, 0);
