@@ -254,6 +254,9 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     __syncthreads();
     const int qpc = F.chroma_qp;
     const int alpha = dbk_alpha_dev[qp], beta = dbk_beta_dev[qp], calpha = dbk_alpha_dev[qpc], cbeta = dbk_beta_dev[qpc];
+    /* tc0 of the three strengths, looked up once (a per-edge table load would sit on the chain of eight dependent edges) */
+    const int tl1 = dbk_tc0_dev[qp][0], tl2 = dbk_tc0_dev[qp][1], tl3 = dbk_tc0_dev[qp][2];
+    const int tc1 = dbk_tc0_dev[qpc][0], tc2 = dbk_tc0_dev[qpc][1], tc3 = dbk_tc0_dev[qpc][2];
     for (int dir = 0; dir < 2; dir++)
         for (int edge = 0; edge < 4; edge++) {
             const uint32_t any = *(const uint32_t *)sbs[dir][edge];
@@ -261,7 +264,7 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
                 if (lane < 16 && alpha && beta) {
                     const int bs = sbs[dir][edge][lane >> 2];
                     if (bs) {
-                        const int tc0 = dbk_tc0_dev[qp][bs - 1];
+                        const int tc0 = bs == 1 ? tl1 : bs == 2 ? tl2 : tl3;
                         uint8_t *q = dir == 0 ? &sy[lane + 4][4 * edge + 4] : &sy[4 * edge + 4][lane + 4];
                         const int xs = dir == 0 ? 1 : 24;
                         const int p2 = q[-3 * xs], p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs], q2 = q[2 * xs];
@@ -276,7 +279,7 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
                 } else if (lane >= 16 && lane < 32 && !(edge & 1) && calpha && cbeta) {
                     const int pl = (lane - 16) >> 3, l = (lane - 16) & 7, bs = sbs[dir][edge][l >> 1];
                     if (bs) {
-                        const int tc = dbk_tc0_dev[qpc][bs - 1] + 1;
+                        const int tc = (bs == 1 ? tc1 : bs == 2 ? tc2 : tc3) + 1;
                         uint8_t *q = dir == 0 ? &sc[pl][l + 4][2 * edge + 4] : &sc[pl][2 * edge + 4][l + 4];
                         const int xs = dir == 0 ? 1 : 16;
                         const int p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs];
