@@ -197,7 +197,9 @@ __device__ static const int8_t dbk_tc0_dev[52][3] = {
  * filtered in order (one line per lane: 16 luma, 8 + 8 chroma on even edges) and the touched pixels go back.
  * Needs (x-1,y), (x,y-1) and (x+1,y-1) filtered: same anti-diagonal order as the search. */
 struct DeblockLDS { uint8_t sy[20][24]; uint8_t sc[2][12][16]; uint8_t sbs[2][4][4]; };
-__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my)
+/* own: the macroblock's unfiltered reconstruction in LDS (MBLocal::pred layout) when pass 2 ran in this wave just before;
+ * nullptr: it is in F.rec like its neighbours */
+__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my, const uint8_t *own = nullptr)
 {
     uint8_t (*sy)[24] = D->sy;              /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
     uint8_t (*sc)[12][16] = D->sc;          /* chroma rows / cols -4..7 */
@@ -207,11 +209,13 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     /* stage: 20 rows x 5 dwords of luma, 2 x 12 rows x 3 dwords of chroma (nothing outside the picture) */
     for (int i = lane; i < 100; i += 64) {
         const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
-        if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = NB_LD32(F.rec[0] + (size_t)(gy + r) * W + gx + c);
+        if (own && r >= 0 && c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = lds4(own + r * 16 + c);
+        else if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = NB_LD32(F.rec[0] + (size_t)(gy + r) * W + gx + c);
     }
     for (int i = lane; i < 72; i += 64) {
         const int pl = i / 36, j = i % 36, r = j / 3 - 4, c = (j % 3) * 4 - 4;
-        if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
+        if (own && r >= 0 && c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = lds4(own + 256 + r * 16 + pl * 8 + c);
+        else if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
     }
     /* boundary strengths */
     const int type = NB_LD8(&F.mb_type[xy]), qp = F.qp;
@@ -456,9 +460,9 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
                 const int mx = fl.unit * x + k;
                 if (mx >= F.mb_w) break;
                 if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels this one reads */
-                mbk_pass2(F, &L, mx, y);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        /* the reconstruction just stored is read back by the filter */
-                mbk_deblock(F, Dp, mx, y);
+                mbk_pass2(F, &L, mx, y, 0);
+                PCAMV_WAVE_SYNC();
+                mbk_deblock(F, Dp, mx, y, L.pred);      /* the unfiltered macroblock goes from LDS to LDS, not through memory */
             }
         }
         PROF_ADD(MODE ? 14 : 1, t_s);

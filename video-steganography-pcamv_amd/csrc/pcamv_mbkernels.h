@@ -158,7 +158,9 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
  * macroblock the skip prediction from the FINAL neighbours; reconstruction; final motion + non-zero flags
  * for the loop filter and for the next frame's temporal candidates.  Same left / top / top-right
  * dependency as the search. */
-PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
+/* store_rec = 0: the loop filter that follows in the same wave takes the reconstruction from L->pred and writes the
+ * filtered macroblock itself */
+PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int store_rec = 1)
 {
     const int xy = mb_y * F.mb_w + mb_x;
     const pcamv_mb_t *r = &F.rec_mb[xy];
@@ -187,7 +189,7 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y)
 #ifdef PCAMV_HOST_EMU
     prim_store_rec(F, L);
 #else
-    prim_store_rec(F, L, true);
+    if (store_rec) prim_store_rec(F, L, true);
 #endif
     /* final motion, type and non-zero flags: read by the neighbours' skip prediction and loop filter in the same
      * launch, so stored write-through like the search's hand-off */
