@@ -192,6 +192,8 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         if (e == hipSuccess) e = hipMemset(b->d_flow, 0, FLOW_CTR_WORDS * sizeof(unsigned));
     }
     if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
+    for (int i = 0; i < n; i++)         /* the kernel instance with --me tesa compiled in exists for the dataflow schedule only */
+        if (ctxs[i]->F.me_method == PCAMV_ME_TESA && !b->sched_flow) { pcamv_gpu_batch_destroy(b); return PCAMV_EUNSUP; }
     *out = b;
     return 0;
 }
@@ -394,7 +396,7 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         if (b->sched_flow) {
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-            if (tesa) hipLaunchKernelGGL(k_analyse_flow_tesa, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
+            if (tesa) pcamv_launch_flow_tesa((unsigned)b->flow_waves, st, dF, b->fl);
             else hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
         } else {
@@ -403,8 +405,7 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
                 int y_hi = d / 2; if (y_hi > F.mb_h - 1) y_hi = F.mb_h - 1;
                 int cnt = y_hi - y_lo + 1;
                 if (cnt <= 0) continue;
-                if (tesa) hipLaunchKernelGGL(k_search_diag<1>, dim3(cnt, G), dim3(64), 0, st, dF, d);
-                else hipLaunchKernelGGL(k_search_diag<0>, dim3(cnt, G), dim3(64), 0, st, dF, d);
+                hipLaunchKernelGGL(k_search_diag<0>, dim3(cnt, G), dim3(64), 0, st, dF, d);
             }
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
             hipLaunchKernelGGL(k_rca, dim3(F.n_mb * b->slots_per_mb, G), dim3(64), 0, st, dF, b->slots_per_mb);

@@ -23,7 +23,7 @@
  * (macroblock kernels) selects the GOP's FrameDev in a device array.  One launch then carries
  * the same dependency step of all GOPs, which is what fills the 256 CUs (a single 1080p frame
  * exposes at most 60 independent macroblocks at a time). */
-__global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__restrict__ Fs)
+static __global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__restrict__ Fs)
 {
     const FrameDev &F = Fs[blockIdx.z >> 1];
     const int pl = blockIdx.z & 1;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void hpel_load_row(const uint8_t *__restrict__ rowp, 
         }
     }
 }
-__global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__restrict__ Fs)
+static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__restrict__ Fs)
 {
     const FrameDev &F = Fs[blockIdx.z];
     const uint8_t *__restrict__ src = F.raw[0];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64) k_search_diag(const FrameDev *__restrict__
     if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
     mbk_search<TESA>(F, &L, &A, x, y);
 }
-__global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int slots_per_mb)
+static __global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int slots_per_mb)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int
     if (xy >= F.n_mb) return;
     mbk_rca(F, &L, &A, xy, k);
 }
-__global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
+static __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
 }
 
 /* ------------------------------------------------------------------ pass 2 + loop filter */
-__global__ void __launch_bounds__(64) k_pass2_diag(const FrameDev *__restrict__ Fs, int d)
+static __global__ void __launch_bounds__(64) k_pass2_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
     const FrameDev F = Fs[blockIdx.y];
@@ -313,7 +313,7 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
       NB_ST32(dst + (size_t)(cgy - 4 + r) * CW + cgx + c, *(const uint32_t *)&sc[pl][r][c + 4]); }
 }
-__global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+static __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ DeblockLDS D;
     const FrameDev F = Fs[blockIdx.y];
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict_
 
 /* both stages of one anti-diagonal in one launch: the filter of (x,y) only needs the pass-2 reconstruction of
  * (x,y) itself and the filtered neighbours of earlier diagonals, and only modifies macroblocks of earlier diagonals */
-__global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__restrict__ Fs, int d)
+static __global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
     __shared__ DeblockLDS D;
@@ -368,7 +368,7 @@ struct FlowDev {
 #define FLOW_ERR 512
 #define FLOW_CTR_WORDS 576
 
-__global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
+static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
 {
     unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= fl.total) return;
@@ -491,24 +491,30 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
     }
 }
 
-__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
     flow_loop<0, 0>(Fs, fl, L, &A, nullptr);
 }
-/* the same kernel with --me tesa compiled in (see pcamv_logic.h: the search functions are templates on it) */
-__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa(const FrameDev *__restrict__ Fs, FlowDev fl)
+/* The same kernel with --me tesa compiled in (pcamv_logic.h: the search functions are templates on it) lives in a
+ * translation unit of its own, csrc/pcamv_tesa.hip, built in parallel with this one; the library calls it through
+ * this launcher. */
+#ifdef PCAMV_TESA_TU
+static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
     flow_loop<0, 1>(Fs, fl, L, &A, nullptr);
 }
+#endif
+void pcamv_launch_flow_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the
  * filter reads its neighbourhood with agent-scope loads (NB_LD*).  (With an agent-scope release + acquire per
  * macroblock this was slower than one launch per anti-diagonal: 245 vs 176 ms per closed-loop step at G=256.) */
-__global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ DeblockLDS D;
@@ -517,7 +523,7 @@ __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */
-__global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__ Fs, const int *__restrict__ req, int *__restrict__ out)
+static __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__ Fs, const int *__restrict__ req, int *__restrict__ out)
 {
     __shared__ MBLocal L;
     const FrameDev F = Fs[0];
@@ -592,7 +598,7 @@ __device__ int dev_stc_matrix(int width, int height, unsigned *cols, long long *
     return 1;
 }
 
-__global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restrict__ Es)
+static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restrict__ Es)
 {
     const EmbedDev E = Es[blockIdx.x];
     __shared__ int s_cnt[1024];
@@ -811,7 +817,7 @@ __global__ void __launch_bounds__(1024 / NS) k_stc_forward(const EmbedDev *__res
  * word w of every row in lane w, so the serial walk is scalar code around one v_readlane per column; the
  * column's constants (colinfo) come from the lane of the same number.  The walk's state is wave-uniform: the
  * compiler keeps it in SGPRs. */
-__global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__restrict__ Es)
+static __global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__restrict__ Es)
 {
     const EmbedDev E = Es[blockIdx.x];
     const int lane = threadIdx.x;

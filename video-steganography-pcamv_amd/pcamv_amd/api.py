@@ -114,15 +114,25 @@ def lib_path():
 
 
 def build_library(force=False):
-    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip into the in-tree libpcamv_gpu.so."""
+    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa kernels, compiled side
+    by side) into the in-tree libpcamv_gpu.so."""
     out = lib_path()
-    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))]
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if not f.endswith(".o")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "pcamv_gpu.h"))
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-           "-Wno-unused-value", "-Wno-unused-result", "-o", out, os.path.join(_CSRC, "pcamv_gpu.hip")]
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+    objs, procs = [], []
+    for unit in ("pcamv_gpu", "pcamv_tesa"):
+        obj = os.path.join(_CSRC, unit + ".o")
+        objs.append(obj)
+        procs.append(subprocess.Popen(["hipcc", *flags, "-c", "-o", obj, os.path.join(_CSRC, unit + ".hip")]))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise subprocess.CalledProcessError(max(rcs), "hipcc -c (csrc/*.hip)")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, *objs])
+    for obj in objs:
+        os.remove(obj)
     return out
 
 
