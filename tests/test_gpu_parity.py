@@ -164,6 +164,14 @@ def test_embedding_edge_cases(pc):
         assert np.array_equal(a[k], b[k])
     assert np.array_equal(a["message"], msg)
     n = a["n"]
+    # short messages: below 10 bits the reference's forward and backward passes shorten the last columns differently
+    # (embed.h:462 vs 523) -- reproduced, not fixed; few bits over many MVs: sub-matrix widths beyond the 20 tabulated
+    # ones (random columns from the LCG, up to 256 wide, embed.h:286)
+    for bits in (2, 3, 5, 7, 9, 10, 11):
+        a, b = enc.embed_pframe(bits + 0.5), o.embed_pframe(mbs_o, bits + 0.5)
+        assert a["m"] == bits and b["m"] == bits and a["stc_ok"] == b["stc_ok"], bits
+        for k in ("message", "stego", "flip"):
+            assert np.array_equal(a[k], b[k]), (bits, k)
     a, b = enc.embed_pframe(float(n + 5)), o.embed_pframe(mbs_o, float(n + 5))
     assert a["stc_ok"] == 0 and b["stc_ok"] == 0 and np.array_equal(a["flip"], a["cover"].astype(np.int8)) and np.array_equal(a["flip"], b["flip"])
     # identical frames, no noise: every MB becomes P_SKIP, no carriers

@@ -263,7 +263,7 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     HIPCHK(c, dalloc(&c->d_cover, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_stego, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_message, (size_t)c->cap));
     HIPCHK(c, dalloc(&c->d_user_msg, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_colinfo, (size_t)c->cap));
     HIPCHK(c, dalloc(&c->d_rho, (size_t)c->cap)); HIPCHK(c, dalloc(&c->d_flip, (size_t)c->cap));
-    HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 72)); HIPCHK(c, dalloc(&c->d_lcg, 1));
+    HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 2 * STC_MAXW + 8)); HIPCHK(c, dalloc(&c->d_lcg, 1));
     HIPCHK(c, dalloc(&c->d_path, (size_t)c->cap * 32));
     HIPCHK(c, dalloc(&c->d_nnz, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_car_base, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_flip_user, (size_t)c->cap));
     HIPCHK(c, hipMemset(c->d_nnz, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_car_base, 0, (size_t)F.n_mb * 4));

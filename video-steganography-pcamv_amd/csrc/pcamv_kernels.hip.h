@@ -547,11 +547,13 @@ static __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__res
 }
 
 /* ------------------------------------------------------------------ embedding stage */
+#define STC_MAXW 256
 struct EmbedDev {
     const pcamv_mb_t *mbs; int n_mb;
     uint8_t *cover, *stego, *message; float *rho; int8_t *flip;
     int *hdr;                 /* [0]=n [1]=m [2]=stc_ok [3]=num_flip [4]=sum(width) [6..7]=(double) sum of rho over the trellis */
-    unsigned *cols;           /* [2][32] columns of the two sub-matrices; cols[64]=shorter, cols[65]=longer */
+    unsigned *cols;           /* [2][STC_MAXW] columns of the two sub-matrices (getMatrix allows widths up to 2^(h-2) = 256, embed.h:286);
+                               * cols[2 * STC_MAXW] = shorter, cols[2 * STC_MAXW + 1] = longer */
     unsigned *path;           /* n * 32 words */
     int *rnd;                 /* glibc rand state: r[0..30], f, b */
     long long *lcg;           /* STC column LCG state (embed.h:134) */
@@ -560,7 +562,7 @@ struct EmbedDev {
     int cap;                  /* capacity of the per-carrier arrays */
     int *car_base;            /* [n_mb] index of each macroblock's first carrier (pass 2 finds its flips there) */
     unsigned *colinfo;        /* per trellis column, what both Viterbi passes need of it in one word: the (shortened)
-                               * matrix column [9:0], cover bit [10], "last column of its message bit" [11], that
+                               * matrix column as the forward pass uses it [9:0] and as the backward pass does [22:13], cover bit [10], "last column of its message bit" [11], that
                                * message bit [12] */
 };
 
@@ -582,7 +584,7 @@ __device__ int dev_stc_matrix(int width, int height, unsigned *cols, long long *
         for (int i = 0; i < width; i++) cols[i] = pcamv_stc_mats_dev[(height - 7) * 400 + (width - 1) * 20 + i];
         return 1;
     }
-    if (width > 32 || (1 << (height - 2)) < width) return 0;
+    if ((1 << (height - 2)) < width) return 0;
     unsigned mask = (1u << (height - 2)) - 1, bop = (1u << (height - 1)) + 1;
     long hold = (long)*lcg;
     for (int i = 0; i < width; i++) {
@@ -681,8 +683,8 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
 #define STC_BEFORE(i) ((i) == 0 ? 0 : (int)floor((i) * invalpha + 0.5))
     const int nproc = sched ? STC_BEFORE(m) : 0;
     if (t == 64) {
-        const int ok = sched && dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + 32, E.lcg);
-        if (ok) { E.cols[64] = shorter; E.cols[65] = longer; }
+        const int ok = sched && dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + STC_MAXW, E.lcg);
+        if (ok) { E.cols[2 * STC_MAXW] = shorter; E.cols[2 * STC_MAXW + 1] = longer; }
         E.hdr[0] = n; E.hdr[1] = m; E.hdr[3] = 0;
         E.hdr[4] = ok ? nproc : 0; E.hdr[2] = ok ? -1 : 0;          /* -1: schedule valid, Viterbi pending */
         s_ok = ok;
@@ -715,10 +717,16 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
     for (int i = t; i < m; i += 1024) {
         const int start = STC_BEFORE(i);
         const int which = (double)(start + longer) <= (i + 1) * invalpha + 0.5, width = which ? longer : shorter;
-        const int left = m - i;                                   /* the last 10 message bits use shortened columns (embed.h:462) */
-        const unsigned colmask = left >= 10 ? 1023u : (1u << left) - 1, msg = E.message[i] ? 4096u : 0u;
-        for (int k = 0; k < width; k++)
-            E.colinfo[start + k] = (E.cols[which * 32 + k] & colmask) | (E.cover[start + k] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | msg;
+        /* shortened columns near the end of the message.  The forward pass drops one row after every message bit i with
+         * m - i <= 10 (embed.h:462), the backward pass adds one row back per such bit from the end (embed.h:523): the same
+         * mask when m >= 10, not for shorter messages -- the reference's own arithmetic, kept (its stego then does not
+         * carry the message) */
+        const int left = m - i, drops = imax(0, i - imax(0, m - 10));
+        const unsigned fmask = 1023u >> drops, bmask = left >= 10 ? 1023u : (1u << left) - 1, msg = E.message[i] ? 4096u : 0u;
+        for (int k = 0; k < width; k++) {
+            const unsigned col = E.cols[which * STC_MAXW + k];
+            E.colinfo[start + k] = (col & fmask) | (E.cover[start + k] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | msg | (col & bmask) << 13;
+        }
     }
 #undef STC_BEFORE
     if (t >= 960) {         /* the price of flipping everything, summed in column order like embed.h:448 (the Viterbi's
@@ -840,7 +848,7 @@ static __global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__re
                     const unsigned inf = __builtin_amdgcn_readlane(info, e);
                     if (inf & 2048u) state = (state << 1) | (inf >> 12 & 1);
                     const unsigned word = __builtin_amdgcn_readlane(row[e], (state >> 5) & 31);
-                    if (word >> (state & 31) & 1) { out |= 1ull << e; state ^= inf & 1023u; }
+                    if (word >> (state & 31) & 1) { out |= 1ull << e; state ^= inf >> 13 & 1023u; }
                 }
             }
             if (lane < cnt) {       /* stego bit and flip map (encoder.c:1848-1855) of this chunk */
