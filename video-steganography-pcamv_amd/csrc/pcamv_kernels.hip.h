@@ -674,6 +674,7 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
      * two agree in the same double arithmetic), so message bits are independent and only the message itself (a
      * lagged-Fibonacci generator) and the sum of rho stay serial, one wave each. */
     __shared__ unsigned s_rnd[64];
+    __shared__ unsigned s_cols[2 * STC_MAXW];
     __shared__ int s_ok;
     int m = E.emrate > 1.0f ? (int)E.emrate : (int)__fmul_rn(E.emrate, (float)n);
     if (m < 0) m = 0;
@@ -683,8 +684,14 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
 #define STC_BEFORE(i) ((i) == 0 ? 0 : (int)floor((i) * invalpha + 0.5))
     const int nproc = sched ? STC_BEFORE(m) : 0;
     if (t == 64) {
-        const int ok = sched && dev_stc_matrix(shorter, 10, E.cols, E.lcg) && dev_stc_matrix(longer, 10, E.cols + STC_MAXW, E.lcg);
-        if (ok) { E.cols[2 * STC_MAXW] = shorter; E.cols[2 * STC_MAXW + 1] = longer; }
+        /* (built in LDS: the random-column generator compares every new column with all earlier ones, a serial walk
+         * that should not go through global memory) */
+        const int ok = sched && dev_stc_matrix(shorter, 10, s_cols, E.lcg) && dev_stc_matrix(longer, 10, s_cols + STC_MAXW, E.lcg);
+        if (ok) {
+            for (int k = 0; k < shorter; k++) E.cols[k] = s_cols[k];
+            for (int k = 0; k < longer; k++) E.cols[STC_MAXW + k] = s_cols[STC_MAXW + k];
+            E.cols[2 * STC_MAXW] = shorter; E.cols[2 * STC_MAXW + 1] = longer;
+        }
         E.hdr[0] = n; E.hdr[1] = m; E.hdr[3] = 0;
         E.hdr[4] = ok ? nproc : 0; E.hdr[2] = ok ? -1 : 0;          /* -1: schedule valid, Viterbi pending */
         s_ok = ok;
@@ -724,7 +731,7 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
         const int left = m - i, drops = imax(0, i - imax(0, m - 10));
         const unsigned fmask = 1023u >> drops, bmask = left >= 10 ? 1023u : (1u << left) - 1, msg = E.message[i] ? 4096u : 0u;
         for (int k = 0; k < width; k++) {
-            const unsigned col = E.cols[which * STC_MAXW + k];
+            const unsigned col = s_cols[which * STC_MAXW + k];
             E.colinfo[start + k] = (col & fmask) | (E.cover[start + k] ? 1024u : 0u) | (k == width - 1 ? 2048u : 0u) | msg | (col & bmask) << 13;
         }
     }
