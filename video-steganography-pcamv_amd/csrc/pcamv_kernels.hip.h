@@ -461,6 +461,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
                 if (mx >= F.mb_w) break;
                 if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels this one reads */
                 mbk_pass2(F, &L, mx, y, 0);
+                /* (the filter reads back this macroblock's own final motion / non-zero flags through memory: same wave,
+                 * program order, same agent-scope path -- no counter wait needed, only the compiler's ordering) */
                 PCAMV_WAVE_SYNC();
                 mbk_deblock(F, Dp, mx, y, L.pred);      /* the unfiltered macroblock goes from LDS to LDS, not through memory */
             }
