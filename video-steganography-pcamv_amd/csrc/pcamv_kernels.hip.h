@@ -197,10 +197,11 @@ __device__ static const int8_t dbk_tc0_dev[52][3] = {
  * filtered in order (one line per lane: 16 luma, 8 + 8 chroma on even edges) and the touched pixels go back.
  * Needs (x-1,y), (x,y-1) and (x+1,y-1) filtered: same anti-diagonal order as the search. */
 struct DeblockLDS { uint8_t sy[20][24]; uint8_t sc[2][12][16]; uint8_t sbs[2][4][4]; };
-/* own: the macroblock's unfiltered reconstruction in LDS (MBLocal::pred layout) when pass 2 ran in this wave just before;
- * nullptr: it is in F.rec like its neighbours */
-__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my, const uint8_t *own = nullptr)
+/* Lo: the MBLocal pass 2 of this macroblock has just run in (same wave): its unfiltered reconstruction (pred), type, final
+ * motion and non-zero flags are taken from there; nullptr: everything is in memory like the neighbours' */
+__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my, const MBLocal *Lo = nullptr)
 {
+    const uint8_t *own = Lo ? Lo->pred : nullptr;
     uint8_t (*sy)[24] = D->sy;              /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
     uint8_t (*sc)[12][16] = D->sc;          /* chroma rows / cols -4..7 */
     uint8_t (*sbs)[4][4] = D->sbs;
@@ -218,7 +219,7 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
         else if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
     }
     /* boundary strengths */
-    const int type = NB_LD8(&F.mb_type[xy]), qp = F.qp;
+    const int type = Lo ? Lo->i_type : (int)NB_LD8(&F.mb_type[xy]), qp = F.qp;
     const int qp_thresh = 15 - (F.chroma_qp_offset > 0 ? F.chroma_qp_offset : 0);
     const int edge_end = (type == PCAMV_P_SKIP || qp <= qp_thresh) ? 1 : 4;
     const int no_sub8x8 = type != PCAMV_P_8x8 || !(F.inter & PCAMV_ANALYSE_PSUB8x8);
@@ -231,13 +232,22 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
             const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
             const int nxy = edge ? xy : (dir ? xy - F.mb_w : xy - 1);
             const int bi = (x & 1) + 2 * (y & 1) + 4 * (x >> 1) + 8 * (y >> 1), bn = (xn & 1) + 2 * (yn & 1) + 4 * (xn >> 1) + 8 * (yn >> 1);
-            if (((NB_LD16(&F.nnz[xy]) >> bi) & 1) || ((NB_LD16(&F.nnz[nxy]) >> bn) & 1)) bs = 2;
+            const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
+            const int fx = 4 * mx + x, fy = 4 * my + y, fxn = dir == 0 ? fx - 1 : fx, fyn = dir == 0 ? fy : fy - 1;
+            /* both sides of the edge: flags, motion, reference -- this macroblock's from LDS when it has just been made
+             * here, the rest in one round of loads (not one per test) */
+            const bool nb_local = Lo && edge;
+            const int c8a = SCAN8_0 + x + 8 * y, c8b = SCAN8_0 + xn + 8 * yn;
+            const unsigned nz_a = Lo ? (unsigned)Lo->nnz_mask : (unsigned)NB_LD16(&F.nnz[xy]);
+            const unsigned nz_b = nb_local ? (unsigned)Lo->nnz_mask : (unsigned)NB_LD16(&F.nnz[nxy]);
+            const uint32_t wa = Lo ? NB_PACK16(Lo->cmv[c8a][0], Lo->cmv[c8a][1]) : NB_LD32(F.mv + 2 * (fy * s4 + fx));
+            const uint32_t wb = nb_local ? NB_PACK16(Lo->cmv[c8b][0], Lo->cmv[c8b][1]) : NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
+            const int ra = Lo ? (int)Lo->cref[c8a] : (int)NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]);
+            const int rb = nb_local ? (int)Lo->cref[c8b] : (int)NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]);
+            if (((nz_a >> bi) & 1) || ((nz_b >> bn) & 1)) bs = 2;
             else if (!(edge & no_sub8x8)) {
-                const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
-                const int fx = 4 * mx + x, fy = 4 * my + y, fxn = dir == 0 ? fx - 1 : fx, fyn = dir == 0 ? fy : fy - 1;
-                const uint32_t wa = NB_LD32(F.mv + 2 * (fy * s4 + fx)), wb = NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
                 const int a0 = (int16_t)(wa & 0xffff), a1 = (int16_t)(wa >> 16), b0 = (int16_t)(wb & 0xffff), b1 = (int16_t)(wb >> 16);
-                if (NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]) != NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]) || iabs(a0 - b0) >= 4 || iabs(a1 - b1) >= 4) bs = 1;
+                if (ra != rb || iabs(a0 - b0) >= 4 || iabs(a1 - b1) >= 4) bs = 1;
                 bs |= 0x10;              /* marks "decided by the motion test" for the copy rule below */
             }
         }
@@ -461,10 +471,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
                 if (mx >= F.mb_w) break;
                 if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels this one reads */
                 mbk_pass2(F, &L, mx, y, 0);
-                /* (the filter reads back this macroblock's own final motion / non-zero flags through memory: same wave,
-                 * program order, same agent-scope path -- no counter wait needed, only the compiler's ordering) */
                 PCAMV_WAVE_SYNC();
-                mbk_deblock(F, Dp, mx, y, L.pred);      /* the unfiltered macroblock goes from LDS to LDS, not through memory */
+                mbk_deblock(F, Dp, mx, y, &L);          /* the unfiltered macroblock goes from LDS to LDS, not through memory */
             }
         }
         PROF_ADD(MODE ? 14 : 1, t_s);
