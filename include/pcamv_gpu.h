@@ -53,6 +53,7 @@ enum { PCAMV_ME_DIA = 0, PCAMV_ME_HEX = 1, PCAMV_ME_UMH = 2, PCAMV_ME_ESA = 3, P
 enum { PCAMV_P_L0 = 4, PCAMV_P_8x8 = 5, PCAMV_P_SKIP = 6 };
 enum { PCAMV_D_L0_4x4 = 0, PCAMV_D_L0_8x4 = 1, PCAMV_D_L0_4x8 = 2, PCAMV_D_L0_8x8 = 3,
        PCAMV_D_8x8 = 13, PCAMV_D_16x8 = 14, PCAMV_D_8x16 = 15, PCAMV_D_16x16 = 16 };
+#define PCAMV_ANALYSE_I4x4      0x0001u   /* x264.h:97: intra 4x4 SATD analysis (only its cost is used, from subme 6 on) */
 #define PCAMV_ANALYSE_PSUB16x16 0x0010u   /* x264.h:99  */
 #define PCAMV_ANALYSE_PSUB8x8   0x0020u   /* x264.h:100 */
 
@@ -62,17 +63,19 @@ typedef struct pcamv_params_t {
     int32_t i_width, i_height;        /* luma size, multiples of 16                              */
     int32_t i_me_method;              /* analyse.i_me_method  (PCAMV_ME_*, all five)             */
     int32_t i_me_range;               /* analyse.i_me_range   (default 16, common.c:121); <= 16 with PCAMV_ME_TESA */
-    int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..5 here (>=6 needs RDO: next)*/
+    int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..7 (6 and 7 are the same for P frames: RD mode decision) */
     int32_t i_mv_range;               /* analyse.i_mv_range after level lookup, encoder.c:558    */
     int32_t b_chroma_me;              /* analyse.b_chroma_me  (default 1)                        */
     int32_t b_fast_pskip;             /* analyse.b_fast_pskip (default 1)                        */
     int32_t b_dct_decimate;           /* analyse.b_dct_decimate (default 1)                      */
-    int32_t b_cabac;                  /* b_cabac (default 1): only the P8x8 ref-cost term        */
-    uint32_t inter;                   /* analyse.inter & (PSUB16x16|PSUB8x8)                     */
+    int32_t b_cabac;                  /* b_cabac (default 1): entropy coder whose sizes the RD mode decision uses */
+    uint32_t inter;                   /* analyse.inter & (I4x4|PSUB16x16|PSUB8x8)                */
     int32_t i_chroma_qp_offset;       /* analyse.i_chroma_qp_offset                              */
     int32_t i_luma_deadzone[2];       /* analyse.i_luma_deadzone {inter,intra} = {21,11}         */
     int32_t i_tscale;                 /* temporal-candidate scale (common/macroblock.c:454); 256
                                          for consecutive P frames, 0 = previous frame was intra  */
+    int32_t i_psy_rd;                 /* h->mb.i_psy_rd = FIX8(analyse.f_psy_rd) (encoder.c:515): 256 by default from subme 6 on,
+                                         0 below; the caller also lowers i_chroma_qp_offset as encoder.c:520-521 does */
 } pcamv_params_t;
 
 /* One macroblock of the pass-1 record: same members, order of blocks and meaning as

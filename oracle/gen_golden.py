@@ -39,12 +39,15 @@ def mv_field(mbs, mbw, mbh):
     return mvf, np.zeros((mbh * 2, mbw * 2), np.int8)
 
 
-def analysis_fixture(name, W, H, me, subme, qp, inter, seed, static_cols, me_range=16, noise=6, frames=2):
+def analysis_fixture(name, W, H, me, subme, qp, inter, seed, static_cols, me_range=16, noise=6, frames=2, cabac=1, psy_rd=1.0, embed=1):
     clip = make_clip(W, H, frames + 1, seed=seed, static_cols=static_cols, noise=noise)
     mvr = orc.level_mv_range(W, H)
-    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, embed=1, inter_flags=inter | 0x1 | 0x100, me_range=me_range)
+    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, embed=embed, inter_flags=inter | 0x1 | 0x100, me_range=me_range,
+                 cabac=cabac, psy_rd=psy_rd)
+    hashes = r.debug_state_hash() if subme >= 6 and cabac else None
     ref, prev = clip[0], None
-    d = dict(width=W, height=H, me=refh.ME[me], subme=subme, qp=qp, inter=inter, mv_range=mvr, me_range=me_range, frames=frames)
+    d = dict(width=W, height=H, me=refh.ME[me], subme=subme, qp=qp, inter=inter, mv_range=mvr, me_range=me_range, frames=frames,
+             cabac=cabac, psy_rd_fix8=r.psy_fix8, chroma_qp_offset=r.chroma_qp_offset, embed=embed)
     for t in range(1, frames + 1):
         if prev is None:
             r.set_ref(*ref)
@@ -60,6 +63,8 @@ def analysis_fixture(name, W, H, me, subme, qp, inter, seed, static_cols, me_ran
         if prev is not None:
             d[f"f{t}_prev_mv"], d[f"f{t}_prev_ref"] = prev
         d[f"f{t}_mbs"] = mbs
+        if hashes is not None:
+            d[f"f{t}_cabac_state_hash"] = hashes.copy()     # FNV-1a of the 460 context states after every macroblock
         d[f"f{t}_plane_sha"] = np.array([sha(planes[k]) for k in range(4)])
         # interior + filtered margin of the integral plane is what the search can touch
         if integ is not None:
@@ -146,10 +151,51 @@ def primitive_fixture():
     print("primitives: me cases", len(cases))
 
 
+def rd_primitive_fixture():
+    """what --subme >= 6 adds below the macroblock level: intra prediction (common/predict.c), sa8d / hadamard_ac
+    (common/pixel.c:256-358), the P-slice CABAC context initialisation"""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    r = refh.Ref(176, 144, embed=0)
+    L = refh.lib()
+    d = {}
+    bufs, outs, kinds = [], [], []
+    for kind, nmodes in ((0, 7), (1, 7), (2, 12)):
+        for mode in range(nmodes):
+            for it in range(8):
+                buf = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+                if it % 4 == 3:
+                    buf[:] = rng.integers(0, 2, (40, 32)) * 255
+                a = buf.copy()
+                L.refh_predict(r.ctx, kind, mode, C.c_void_p(a.ctypes.data + 8 * 32 + 8))
+                bufs.append(buf); outs.append(a); kinds.append((kind, mode))
+    d.update(ipred_in=np.stack(bufs), ipred_out=np.stack(outs), ipred_kind=np.array(kinds, np.int32))
+    pix = rng.integers(0, 256, (48, 16, 32), dtype=np.uint8)
+    pix[0] = 255; pix[1] = 0; pix[2, ::2] = 255; pix[2, 1::2] = 0; pix[3, :, ::2] = 255; pix[3, :, 1::2] = 0
+    other = rng.integers(0, 256, (48, 16, 16), dtype=np.uint8)
+    hac = np.zeros((48, 4, 2), np.uint32); sa8d = np.zeros((48, 2), np.int32)
+    for i in range(48):
+        for ip in range(4):
+            L.refh_hadamard_ac(r.ctx, ip, C.c_void_p(pix[i].ctypes.data), 32, C.c_void_p(hac[i, ip].ctypes.data))
+        for k, ip in enumerate((0, 3)):
+            sa8d[i, k] = L.refh_sa8d(r.ctx, ip, C.c_void_p(pix[i].ctypes.data), 32, C.c_void_p(other[i].ctypes.data), 16)
+    d.update(hac_pix=pix, hac_other=other, hac_res=hac, sa8d_res=sa8d)
+    np.savez_compressed(os.path.join(OUT, "primitives_rd.npz"), **d)
+    print("primitives_rd:", len(bufs), "predictions")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if not refh.available():
         sys.exit("oracle/_ref/libpcamv_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    if "--rd-only" in sys.argv:
+        rd_primitive_fixture()
+        analysis_fixture("qcif_hex_subme6", 176, 144, "hex", 6, 26, 0x10, 5, 48)
+        analysis_fixture("qcif_umh_subme7_cavlc", 176, 144, "umh", 7, 24, 0x10, 11, 0, cabac=0, noise=25)
+        analysis_fixture("qcif_dia_subme6_nopsy_noisy", 176, 144, "dia", 6, 30, 0x10, 33, 32, psy_rd=0.0, noise=40)
+        analysis_fixture("qcif_esa_subme6_noembed", 176, 144, "esa", 6, 28, 0x10, 2, 16, embed=0)
+        analysis_fixture("cif_umh_subme7", 352, 288, "umh", 7, 26, 0x10, 7, 64)
+        sys.exit(0)
     primitive_fixture()
     analysis_fixture("qcif_hex_subme5", 176, 144, "hex", 5, 26, 0x10, 5, 48)
     analysis_fixture("qcif_dia_subme2", 176, 144, "dia", 2, 22, 0x10, 9, 0)

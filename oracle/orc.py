@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpcamv_oracle.so")
 ME = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}
 PIXEL = {"16x16": 0, "16x8": 1, "8x16": 2, "8x8": 3, "8x4": 4, "4x8": 5, "4x4": 6}
 P_L0, P_8x8, P_SKIP = 4, 5, 6
-PSUB16x16, PSUB8x8 = 0x10, 0x20
+I4x4, PSUB16x16, PSUB8x8 = 0x01, 0x10, 0x20
 
 
 class Params(C.Structure):
@@ -21,7 +21,7 @@ class Params(C.Structure):
                 ("i_me_range", C.c_int32), ("i_subpel_refine", C.c_int32), ("i_mv_range", C.c_int32),
                 ("b_chroma_me", C.c_int32), ("b_fast_pskip", C.c_int32), ("b_dct_decimate", C.c_int32),
                 ("b_cabac", C.c_int32), ("inter", C.c_uint32), ("i_chroma_qp_offset", C.c_int32),
-                ("i_luma_deadzone", C.c_int32 * 2), ("i_tscale", C.c_int32)]
+                ("i_luma_deadzone", C.c_int32 * 2), ("i_tscale", C.c_int32), ("i_psy_rd", C.c_int32)]
 
 
 class Embed(C.Structure):
@@ -38,15 +38,21 @@ MB_DTYPE = np.dtype([("i_type", "<i4"), ("i_partition", "<i4"), ("i_qp", "<i4"),
 
 
 def make_params(width, height, me="hex", me_range=16, subme=5, mv_range=None, chroma_me=1,
-                fast_pskip=1, dct_decimate=1, cabac=1, inter=PSUB16x16, chroma_qp_offset=0,
-                tscale=256):
+                fast_pskip=1, dct_decimate=1, cabac=1, inter=PSUB16x16, chroma_qp_offset=None,
+                tscale=256, psy_rd=1.0):
+    """psy_rd / chroma_qp_offset as x264_validate_parameters leaves them (encoder.c:511-522): psy-RD acts from subme 6 on
+    and lowers the chroma QP offset by 2 (1 below strength 0.25)"""
     if mv_range is None:
         mv_range = level_mv_range(width, height)
+    psy = int(psy_rd * 256 + 0.5) if subme >= 6 else 0
+    if chroma_qp_offset is None:
+        chroma_qp_offset = 0 if not psy else (-1 if psy_rd < 0.25 else -2)
     p = Params(width, height, ME[me] if isinstance(me, str) else me, me_range, subme, mv_range,
                chroma_me, fast_pskip, dct_decimate, cabac, inter, chroma_qp_offset)
     p.i_luma_deadzone[0] = 21
     p.i_luma_deadzone[1] = 11
     p.i_tscale = tscale
+    p.i_psy_rd = psy
     return p
 
 
@@ -123,12 +129,20 @@ class Oracle:
         lib().orc_get_ref_integral(self.ctx, _p(out))
         return out
 
+    def debug_state_hash(self, dump_mb=-1):
+        self._dbg = np.zeros(self.n_mb, np.uint32)
+        self._dump = np.zeros(460, np.uint8)
+        lib().orc_set_debug(self.ctx, _p(self._dbg), dump_mb, _p(self._dump))
+        return self._dbg
+
     def analyse_pframe(self, qp, embed=1):
         mbs = np.zeros(self.n_mb, MB_DTYPE)
         ry = np.zeros((self.h, self.w), np.uint8)
         ru = np.zeros((self.h // 2, self.w // 2), np.uint8)
         rv = np.zeros((self.h // 2, self.w // 2), np.uint8)
-        lib().orc_analyse_pframe(self.ctx, qp, embed, _p(mbs), _p(ry), _p(ru), _p(rv))
+        rc = lib().orc_analyse_pframe(self.ctx, qp, embed, _p(mbs), _p(ry), _p(ru), _p(rv))
+        if rc:
+            raise RuntimeError("orc_analyse_pframe: %d (subme >= 6 with sub-8x8 partitions is not restated)" % rc)
         return mbs, (ry, ru, rv)
 
     def embed_pframe(self, mbs, emrate, message=None):

@@ -35,6 +35,12 @@ static const uint8_t blk_x[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3
 static const uint8_t blk_y[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
 #define SCAN8_0 (4 + 1 * 8)
 static inline int scan8(int idx) { return SCAN8_0 + blk_x[idx] + 8 * blk_y[idx]; }   /* common/common.h:217 */
+/* common/common.h:217-238: position of block idx in the 6x8 neighbour caches (luma 0..15, Cb 16..19, Cr 20..23, luma DC, Cb DC, Cr DC) */
+static const uint8_t scan8_all[27] = {
+    4 + 1 * 8, 5 + 1 * 8, 4 + 2 * 8, 5 + 2 * 8, 6 + 1 * 8, 7 + 1 * 8, 6 + 2 * 8, 7 + 2 * 8,
+    4 + 3 * 8, 5 + 3 * 8, 4 + 4 * 8, 5 + 4 * 8, 6 + 3 * 8, 7 + 3 * 8, 6 + 4 * 8, 7 + 4 * 8,
+    1 + 1 * 8, 2 + 1 * 8, 1 + 2 * 8, 2 + 2 * 8, 1 + 4 * 8, 2 + 4 * 8, 1 + 5 * 8, 2 + 5 * 8,
+    4 + 5 * 8, 5 + 5 * 8, 6 + 5 * 8};
 
 /* analyse.c:148-156 */
 static const int lambda_tab[52] = {
@@ -156,13 +162,19 @@ struct orc {
     int16_t (*mvr)[2];            /* [n_mb] 16x16 results   */
     int16_t (*prev_mv)[2];
     int8_t *prev_ref;
-    int have_prev;
+    int have_prev, ref_is_inter;
     int16_t *cost_mv[52];         /* centre pointers        */
     uint16_t *cost_mv_fpel[52][4];
-    uint16_t quant_mf[2][52][16], quant_bias[2][52][16];   /* [0]=inter luma (CQM_4PY), [1]=inter chroma (CQM_4PC) */
+    uint16_t quant_mf[3][52][16], quant_bias[3][52][16];   /* [0]=inter luma (CQM_4PY), [1]=inter chroma (CQM_4PC), [2]=intra luma (CQM_4IY) */
     int dequant_mf[6][16];
     orc_rand_t rnd;
     int16_t *scratch;
+    /* --subme >= 6: what the entropy coder leaves behind macroblock after macroblock (pcamv_oracle_rd.inc) */
+    uint8_t cabac_state[460];
+    uint8_t (*nnz)[24];           /* [n_mb] luma 0..15 (x264 block order), Cb 16..19, Cr 20..23: non-zero flags (CABAC) / counts (CAVLC) */
+    int16_t *cbp;                 /* [n_mb] h->mb.cbp: luma | chroma << 4 | DC bits << 8 */
+    int16_t (*mvd)[2];            /* [mb_h*4][mb_w*4] */
+    uint32_t *dbg_state_hash; int dbg_mb; uint8_t *dbg_state;
 };
 
 /* analyse.c:193-209: lambda * (2*log2(i+1) + 0.718 + !!i) + .5, with the reference's own
@@ -182,10 +194,10 @@ static void build_quant_tables(orc_t *o)
     static const int qnt[6][3] = {{13107, 8066, 5243}, {11916, 7490, 4660}, {10082, 6554, 4194},
                                   {9362, 5825, 3647},  {8192, 5243, 3355},  {7282, 4559, 2893}};
     /* set.c:77-79: deadzone[CQM_4PY] = 32 - i_luma_deadzone[0], deadzone[CQM_4PC] = 32 - 21 */
-    int dz[2] = {32 - o->p.i_luma_deadzone[0], 32 - 21};
+    int dz[3] = {32 - o->p.i_luma_deadzone[0], 32 - 21, 32 - o->p.i_luma_deadzone[1]};
     for (int q = 0; q < 6; q++)
         for (int i = 0; i < 16; i++) o->dequant_mf[q][i] = deq[q][(i & 1) + ((i >> 2) & 1)] * 16;
-    for (int cat = 0; cat < 2; cat++)
+    for (int cat = 0; cat < 3; cat++)
         for (int q = 0; q < 52; q++)
             for (int i = 0; i < 16; i++) {
                 int base = qnt[q % 6][(i & 1) + ((i >> 2) & 1)];   /* DIV(x*16,16) == x */
@@ -223,6 +235,9 @@ orc_t *orc_open(const pcamv_params_t *p)
     o->prev_mv = calloc((size_t)o->n_mb * 16, sizeof(*o->prev_mv));
     o->prev_ref = malloc((size_t)o->n_mb * 4);
     o->scratch = malloc(sizeof(int16_t) * (4 * 2048 + 64) * 8);
+    o->nnz = calloc(o->n_mb, sizeof(*o->nnz));
+    o->cbp = calloc(o->n_mb, sizeof(*o->cbp));
+    o->mvd = calloc((size_t)o->n_mb * 16, sizeof(*o->mvd));
     build_quant_tables(o);
     orc_srand(&o->rnd, 1);
     return o;
@@ -234,6 +249,7 @@ void orc_close(orc_t *o)
     free(o->lbuf); free(o->cbuf[0]); free(o->cbuf[1]); free(o->ibuf);
     for (int i = 0; i < 3; i++) { free(o->fenc[i]); free(o->frec[i]); }
     free(o->mb_type); free(o->mv); free(o->ref8); free(o->mvr); free(o->prev_mv); free(o->prev_ref); free(o->scratch);
+    free(o->nnz); free(o->cbp); free(o->mvd);
     for (int q = 0; q < 52; q++) {
         if (o->cost_mv[q]) free(o->cost_mv[q] - 2 * 4 * 2048);
         for (int j = 0; j < 4; j++) if (o->cost_mv_fpel[q][j]) free(o->cost_mv_fpel[q][j] - 2 * 2048);
@@ -340,6 +356,7 @@ void orc_set_ref(orc_t *o, const uint8_t *y, const uint8_t *u, const uint8_t *v,
         }
     }
     o->have_prev = prev_mv != NULL && o->p.i_tscale != 0;
+    o->ref_is_inter = prev_mv != NULL;               /* h->fref0[0]->mb_type: the reference is a P picture (the fork codes no intra macroblocks in P slices) */
     if (o->have_prev) {
         memcpy(o->prev_mv, prev_mv, (size_t)o->n_mb * 16 * 2 * sizeof(int16_t));
         memcpy(o->prev_ref, prev_ref, (size_t)o->n_mb * 4);
@@ -374,6 +391,13 @@ typedef struct {
     int b_skip_mc;
     int cbp_luma, cbp_chroma;
     uint8_t nzq[16], nnz[16];                        /* luma 4x4: quantised to non-zero; still non-zero after decimation (h->mb.non_zero_count != 0) */
+    /* --subme >= 6 (pcamv_oracle_rd.inc) */
+    int mbrd, lambda2, b_fast_intra, fenc_satd_sum, fenc_sa8d_sum;
+    int16_t lv[24][16], lvdc[2][4];                  /* h->dct.luma4x4 (zigzag levels; 16..23 chroma with [0] = 0), h->dct.chroma_dc */
+    uint8_t nzc[48];                                 /* h->mb.cache.non_zero_count, 0x80 = unavailable */
+    int16_t cmvd[48][2];                             /* h->mb.cache.mvd */
+    int8_t i4mode[48];                               /* h->mb.cache.intra4x4_pred_mode */
+    int cbp_left, cbp_top;                           /* h->mb.cache.i_cbp_left / top, -1 = unavailable */
 } mbc_t;
 #define NB_LEFT 1
 #define NB_TOP 2
@@ -548,6 +572,35 @@ static void mb_load(orc_t *o, mbc_t *m, int mb_x, int mb_y, int qp)
     m->mv_max_spel[1] = MIN2(m->mv_max_spel[1], fmv * 4);   /* thread_mvy_range == i_fmv_range, 1 thread */
     m->mv_min_fpel[1] = (m->mv_min_spel[1] >> 2) + 5;
     m->mv_max_fpel[1] = (m->mv_max_spel[1] >> 2) - 5;
+
+    m->mbrd = m->subme >= 6;                         /* analyse.c:236 */
+    if (!m->mbrd) return;
+    m->lambda2 = lambda2_tab[qp];
+    /* analyse.c:363-378: no neighbour and no co-located macroblock is ever intra here, so intra is "unlikely" unless the
+     * reference picture is an I frame */
+    m->b_fast_intra = m->mb_xy > 4 && o->ref_is_inter;
+    /* entropy-coder neighbourhood, common/macroblock.c:950-1025, 1170-1200 */
+    static const uint8_t bottom[8] = {10, 11, 14, 15, 18, 19, 22, 23}, right[8] = {5, 7, 13, 15, 17, 19, 21, 23};
+    static const uint8_t top_pos[8] = {4 + 0 * 8, 5 + 0 * 8, 6 + 0 * 8, 7 + 0 * 8, 1 + 0 * 8, 2 + 0 * 8, 1 + 3 * 8, 2 + 3 * 8};
+    static const uint8_t left_pos[8] = {3 + 1 * 8, 3 + 2 * 8, 3 + 3 * 8, 3 + 4 * 8, 0 + 1 * 8, 0 + 2 * 8, 0 + 4 * 8, 0 + 5 * 8};
+    memset(m->nzc, 0, sizeof(m->nzc)); memset(m->cmvd, 0, sizeof(m->cmvd)); memset(m->i4mode, -1, sizeof(m->i4mode));
+    for (int i = 0; i < 8; i++) {
+        m->nzc[top_pos[i]] = (m->neighbour & NB_TOP) ? o->nnz[top][bottom[i]] : 0x80;
+        m->nzc[left_pos[i]] = (m->neighbour & NB_LEFT) ? o->nnz[m->mb_xy - 1][right[i]] : 0x80;
+    }
+    m->cbp_top = (m->neighbour & NB_TOP) ? o->cbp[top] : -1;
+    m->cbp_left = (m->neighbour & NB_LEFT) ? o->cbp[m->mb_xy - 1] : -1;
+    for (int i = 0; i < 4; i++) {
+        if (m->neighbour & NB_TOP) { m->cmvd[SCAN8_0 - 8 + i][0] = o->mvd[t4 + i][0]; m->cmvd[SCAN8_0 - 8 + i][1] = o->mvd[t4 + i][1]; m->i4mode[SCAN8_0 - 8 + i] = 2; }
+        if (m->neighbour & NB_LEFT) { m->cmvd[SCAN8_0 - 1 + 8 * i][0] = o->mvd[b4 - 1 + i * s4][0]; m->cmvd[SCAN8_0 - 1 + 8 * i][1] = o->mvd[b4 - 1 + i * s4][1]; m->i4mode[SCAN8_0 - 1 + 8 * i] = 2; }
+    }
+    /* intra prediction neighbours: the unfiltered pass-1 reconstruction (x264_fdec_filter_row keeps the line above before
+     * the loop filter touches it, encoder.c:1019-1030; the left column is the previous macroblock's fdec buffer) */
+    for (int c = 0; c < 3; c++) {
+        int w = c ? 8 : 16, pw = c ? W / 2 : W, x0 = mb_x * w, y0 = mb_y * w;
+        if (mb_y > 0) for (int x = -1; x < w + w / 2; x++) m->p_fdec[c][x - 32] = o->frec[c][(size_t)(y0 - 1) * pw + clip3(x0 + x, 0, pw - 1)];
+        if (mb_x > 0) for (int y = 0; y < w; y++) m->p_fdec[c][y * 32 - 1] = o->frec[c][(size_t)(y0 + y) * pw + x0 - 1];
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1069,9 +1122,10 @@ static void encode_chroma(mbc_t *m)
           dct[0][0] = dct[1][0] = dct[2][0] = dct[3][0] = 0; }
         for (int i = 0; i < 4; i++) {
             int nz = quant4(dct[i], o->quant_mf[1][qp], o->quant_bias[1][qp]);
+            m->nzc[scan8_all[16 + i + ch * 4]] = nz;
             if (nz) {
                 nz_ac = 1;
-                for (int k = 0; k < 16; k++) lvl[k] = dct[i][zz4[k]];
+                for (int k = 0; k < 16; k++) m->lv[16 + i + ch * 4][k] = lvl[k] = dct[i][zz4[k]];
                 dequant4(dct[i], o->dequant_mf, qp);
                 if (b_decimate) score += decimate_score(lvl + 1, 15);
             }
@@ -1079,11 +1133,14 @@ static void encode_chroma(mbc_t *m)
         { int mf = o->quant_mf[1][qp][0] >> 1, bias = o->quant_bias[1][qp][0] << 1, nz = 0;
           for (int k = 0; k < 4; k++) nz |= quant_dc1(&dc[k], mf, bias);
           nz_dc = !!nz; }
+        m->nzc[scan8_all[25 + ch]] = nz_dc;
+        if (nz_dc) { m->lvdc[ch][0] = dc[0]; m->lvdc[ch][1] = dc[2]; m->lvdc[ch][2] = dc[1]; m->lvdc[ch][3] = dc[3]; }   /* zigzag_scan_2x2_dc, :31-38 */
         /* IDCT_DEQUANT_START (encoder/macroblock.c:40-51); dc[] is d[0][0],d[0][1],d[1][0],d[1][1] */
         int d0 = dc[0] + dc[1], d1 = dc[2] + dc[3], d2 = dc[0] - dc[1], d3 = dc[2] - dc[3];
         int dmf = o->dequant_mf[qp % 6][0], qbits = qp / 6 - 5;
         if (qbits > 0) { dmf <<= qbits; qbits = 0; }
         if ((b_decimate && score < 7) || !nz_ac) {
+            for (int i = 0; i < 4; i++) m->nzc[scan8_all[16 + i + ch * 4]] = 0;
             if (!nz_dc) continue;
             int16_t r[4] = {(int16_t)((d0 + d1) * dmf >> -qbits), (int16_t)((d0 - d1) * dmf >> -qbits),
                             (int16_t)((d2 + d3) * dmf >> -qbits), (int16_t)((d2 - d3) * dmf >> -qbits)};
@@ -1102,7 +1159,7 @@ static void encode_chroma(mbc_t *m)
             for (int i = 0; i < 4; i++) add4x4_idct(dst + (i & 1) * 4 + (i >> 1) * 4 * 32, dct[i]);
         }
     }
-    m->cbp_chroma = any_ac ? 2 : 0;
+    m->cbp_chroma = any_ac ? 2 : (m->nzc[scan8_all[25]] | m->nzc[scan8_all[26]]) ? 1 : 0;   /* :364-372 */
 }
 
 /* x264_macroblock_encode, inter 4x4-transform branch (encoder/macroblock.c:605-612,690-754,771) and
@@ -1120,6 +1177,7 @@ static void mb_encode(mbc_t *m)
         }
         m->cbp_luma = m->cbp_chroma = 0;
         memset(m->nnz, 0, 16);
+        for (int i = 0; i < 27; i++) m->nzc[scan8_all[i]] = 0;
         return;
     }
     if (!m->b_skip_mc) mb_mc(m);
@@ -1135,7 +1193,7 @@ static void mb_encode(mbc_t *m)
             m->nzq[idx] = 0;
             if (quant4(dct[idx], o->quant_mf[0][qp], o->quant_bias[0][qp])) {
                 m->nzq[idx] = 1;
-                for (int k = 0; k < 16; k++) lvl[k] = dct[idx][zz4[k]];
+                for (int k = 0; k < 16; k++) m->lv[idx][k] = lvl[k] = dct[idx][zz4[k]];
                 dequant4(dct[idx], o->dequant_mf, qp);
                 if (b_decimate && dec8 < 6) dec8 += decimate_score(lvl, 16);
                 cbp = 1;
@@ -1156,6 +1214,8 @@ static void mb_encode(mbc_t *m)
                     for (int i4 = 0; i4 < 4; i4++) { int idx = i8 * 4 + i4; add4x4_idct(m->p_fdec[0] + blk_x[idx] * 4 + blk_y[idx] * 4 * 32, dct[idx]); }
     }
     for (int idx = 0; idx < 16; idx++) m->nnz[idx] = m->nzq[idx] && ((m->cbp_luma >> (idx >> 2)) & 1);   /* dropped 8x8s / macroblocks are zeroed (macroblock.c:716-751) */
+    for (int idx = 0; idx < 16; idx++) m->nzc[scan8_all[idx]] = m->nnz[idx];
+    m->nzc[scan8_all[24]] = 0;
     encode_chroma(m);
 }
 /* NOTE (macroblock.c:725-729): with decimation an 8x8 whose blocks quantise to non-zero but
@@ -1213,11 +1273,14 @@ typedef struct {
     me_t me16x16, me8x8[4], me4x4[4][4], me8x4[4][2], me4x8[4][2], me16x8[2], me8x16[2];
     int16_t mvc[5][2];
     int cost8x8, cost16x8, cost8x16, cost4x4[4], cost8x4[4], cost4x8[4];
+    int rd16x16;
 } ana_t;
 
 static void me_setup(me_t *me, int i_pixel, int xoff, int yoff) { memset(me, 0, sizeof(*me)); me->i_pixel = i_pixel; me->xoff = xoff; me->yoff = yoff; }
 
 static void update_cache(mbc_t *m, ana_t *a);   /* analyse.c:3703 */
+static void cache_fenc_satd(mbc_t *m);
+static int rd_cost_mb(mbc_t *m);
 
 /* analyse.c:1122-1204 (one reference).  Returns 1 when the early P_SKIP fired. */
 static int analyse_p16x16(mbc_t *m, ana_t *a, int b_try_pskip)
@@ -1241,6 +1304,14 @@ static int analyse_p16x16(mbc_t *m, ana_t *a, int b_try_pskip)
     o->mvr[m->mb_xy][0] = me.mv[0]; o->mvr[m->mb_xy][1] = me.mv[1];
     cache_ref(m, 0, 0, 4, 4, 0);
     m->i_type = PCAMV_P_L0;
+    if (m->mbrd) {                                /* analyse.c:1194-1203 */
+        cache_fenc_satd(m);
+        if (me.mv[0] == m->pskip_mv[0] && me.mv[1] == m->pskip_mv[1]) {
+            m->i_partition = PCAMV_D_16x16;
+            cache_mv(m, 0, 0, 4, 4, me.mv);
+            a->rd16x16 = rd_cost_mb(m);
+        }
+    }
     return 0;
 }
 /* analyse.c:1371-1426 */
@@ -1446,12 +1517,15 @@ static int rca_mv_cost(mbc_t *m, ana_t *a, me_t *me, int16_t *m_x, int16_t *m_y)
     return cost_opt;
 }
 
-/* x264_macroblock_analyse, P slice, i_mbrd == 0 (analyse.c:2613-2827, 3471, 3518-3689) */
+#include "pcamv_oracle_rd.inc"
+
+/* x264_macroblock_analyse, P slice (analyse.c:2613-2868, 3471, 3518-3689) */
 static void analyse_mb(mbc_t *m, int embed, pcamv_mb_t *out)
 {
     orc_t *o = m->o;
     ana_t A, *a = &A;
     memset(a, 0, sizeof(*a));
+    a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;       /* analyse.c:321-332 */
     int b_skip = 0, b_try_pskip = 0, i_cost;
     unsigned flags = o->p.inter;
     memset(out, 0, sizeof(*out));
@@ -1497,6 +1571,25 @@ static void analyse_mb(mbc_t *m, int embed, pcamv_mb_t *out)
             if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
         }
         m->i_partition = i_partition;
+        if (m->mbrd) {
+            /* analyse.c:2749-2752, 2809-2850: no quarter-pel refinement; the intra SATD cost (never the intra mode) bounds the
+             * RD trials; the partition is decided by x264_rd_cost_mb */
+            int i_satd_inter = i_cost, i16, i4;
+            if (m->b_chroma_me) {
+                int c8 = intra_chroma_cost(m);
+                analyse_intra(m, i_cost - c8, &i16, &i4);
+                i16 += c8; i4 += c8;
+            } else analyse_intra(m, i_cost, &i16, &i4);
+            int i_satd_intra = MIN2(i16, i4);
+            if (getenv("ORC_DBG_MB") && atoi(getenv("ORC_DBG_MB")) == m->mb_xy)
+                fprintf(stderr, "orc intra mb %d inter %d i16 %d i4 %d fast %d costs 16x16 %d 8x8 %d 16x8 %d 8x16 %d\n", m->mb_xy, i_satd_inter, i16, i4, m->b_fast_intra, a->me16x16.cost, a->cost8x8, a->cost16x8, a->cost8x16);
+            analyse_p_rd(m, a, MIN2(i_satd_inter, i_satd_intra), embed);
+            i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x16; i_cost = a->me16x16.cost;
+            if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = PCAMV_D_16x8; }
+            if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_partition = PCAMV_D_8x16; }
+            if (embed && a->cost8x8 < i_cost) { i_cost = a->cost8x8; i_partition = PCAMV_D_8x8; i_type = PCAMV_P_8x8; }   /* analyse.c:2841-2842: only while embedding */
+            m->i_partition = i_partition;
+        } else
         if (i_partition == PCAMV_D_16x16) me_refine_qpel(m, &a->me16x16);
         else if (i_partition == PCAMV_D_16x8) { me_refine_qpel(m, &a->me16x8[0]); me_refine_qpel(m, &a->me16x8[1]); }
         else if (i_partition == PCAMV_D_8x16) { me_refine_qpel(m, &a->me8x16[0]); me_refine_qpel(m, &a->me8x16[1]); }
@@ -1538,6 +1631,15 @@ static void analyse_mb(mbc_t *m, int embed, pcamv_mb_t *out)
     }
     /* the pass-1 encode of the MB (encoder.c after analyse) and x264_macroblock_cache_save */
     mb_encode(m);
+    if (m->mbrd) {
+        entropy_commit(m);
+        if (o->dbg_state_hash) {
+            uint32_t hsh = 2166136261u;
+            for (int i = 0; i < 460; i++) hsh = (hsh ^ o->cabac_state[i]) * 16777619u;
+            o->dbg_state_hash[m->mb_xy] = hsh;
+        }
+        if (o->dbg_state && m->mb_xy == o->dbg_mb) memcpy(o->dbg_state, o->cabac_state, 460);
+    }
     for (int i = 0; i < 16; i++) {
         if (!embed || m->i_type == PCAMV_P_SKIP) { out->mv[i][0] = m->cmv[scan8(i)][0]; out->mv[i][1] = m->cmv[scan8(i)][1]; out->ref[i] = m->cref[scan8(i)]; }
     }
@@ -1554,10 +1656,16 @@ static void analyse_mb(mbc_t *m, int embed, pcamv_mb_t *out)
         for (int y = 0; y < 8; y++) memcpy(o->frec[c] + (size_t)(m->mb_y * 8 + y) * (W / 2) + m->mb_x * 8, m->p_fdec[c] + y * 32, 8);
 }
 
+void orc_set_debug(orc_t *o, uint32_t *state_hash, int dump_mb, uint8_t *dump_state) { o->dbg_state_hash = state_hash; o->dbg_mb = dump_mb; o->dbg_state = dump_state; }
 int orc_analyse_pframe(orc_t *o, int qp, int embed, pcamv_mb_t *out_mb, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v)
 {
     mbc_t *m = malloc(sizeof(*m));
+    memset(m, 0, sizeof(*m));
     memset(o->mb_type, PCAMV_P_SKIP, o->n_mb);
+    if (o->p.i_subpel_refine >= 6) {
+        if ((o->p.inter & PCAMV_ANALYSE_PSUB8x8)) { free(m); return -5; }      /* sub-8x8 RD (x264_rd_cost_part) not restated */
+        orc_cabac_init_p(o->cabac_state, qp);                                 /* x264_cabac_context_init at the slice start, encoder.c:1227 */
+    }
     for (int my = 0; my < o->mb_h; my++)
         for (int mx = 0; mx < o->mb_w; mx++) {
             mb_load(o, m, mx, my, qp);

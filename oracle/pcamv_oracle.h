@@ -32,6 +32,8 @@ void orc_get_ref_integral(const orc_t *o, uint16_t *out);
 
 int  orc_analyse_pframe(orc_t *o, int qp, int embed, pcamv_mb_t *out_mb,
                         uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v);
+/* diagnostics: FNV-1a of the 460 CABAC context states after every macroblock (subme >= 6, b_cabac) */
+void orc_set_debug(orc_t *o, uint32_t *state_hash, int dump_mb, uint8_t *dump_state /* [460] or NULL */);
 int  orc_embed_pframe(orc_t *o, const pcamv_mb_t *mbs, float emrate, const uint8_t *message, int message_len,
                       pcamv_embed_t *out);
 int orc_pass2_pframe(orc_t *o, int qp, const pcamv_mb_t *mbs, const uint8_t *flips, int n_flips, pcamv_mb_t *out, uint8_t *nnz,
@@ -52,6 +54,10 @@ int  orc_rand(orc_rand_t *s);
 int  orc_sad(int i_pixel, const uint8_t *a, int sa, const uint8_t *b, int sb);
 int  orc_satd(int i_pixel, const uint8_t *a, int sa, const uint8_t *b, int sb);
 int  orc_ssd(int i_pixel, const uint8_t *a, int sa, const uint8_t *b, int sb);
+int  orc_sa8d(int i_pixel, const uint8_t *a, int sa, const uint8_t *b, int sb);              /* PIX_16x16, PIX_8x8 */
+uint64_t orc_hadamard_ac(int i_pixel, const uint8_t *pix, int stride);                        /* PIX_16x16 .. PIX_8x8 */
+void orc_predict(int kind, int mode, uint8_t *dst /* stride 32, neighbours in place */);     /* 0: 16x16, 1: chroma 8x8, 2: 4x4 */
+void orc_cabac_init_p(uint8_t *state /* [460] */, int qp);
 void orc_mc_luma(uint8_t *dst, int ds, uint8_t *const src[4], int ss, int mvx, int mvy, int w, int h);
 void orc_mc_chroma(uint8_t *dst, int ds, const uint8_t *src, int ss, int mvx, int mvy, int w, int h);
 void orc_cost_mv_table(int qp, int16_t *out /* [4*4*2048+1] */);

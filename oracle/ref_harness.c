@@ -21,6 +21,22 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* encoder/rdo.c (pulled in by analyse.c) turns the bit writers into size counters with macros and leaves them
+ * defined; this file calls the real writers of encoder/cabac.c / cavlc.c / common/bs.h again */
+#undef bs_write1
+#undef bs_write
+#undef bs_write_ue
+#undef bs_write_se
+#undef bs_write_te
+#undef x264_macroblock_write_cavlc
+#undef x264_macroblock_write_cabac
+#undef x264_cabac_encode_decision
+#undef x264_cabac_encode_decision_noup
+#undef x264_cabac_encode_terminal
+#undef x264_cabac_encode_bypass
+#undef x264_cabac_encode_ue_bypass
+#undef x264_cabac_encode_flush
+
 /* H.264 Table 8-15 (QPc as a function of qPI), padded by 12 on each side the way every
  * H.264 codec indexes it with a chroma offset in [-12,12]. Spec data, not reference text. */
 static const uint8_t refh_chroma_qp_tab[52 + 24] = {
@@ -34,6 +50,9 @@ typedef struct {
     x264_t *h;
     int width, height, mb_w, mb_h;
     int have_prev;
+    uint32_t *dbg_state_hash;      /* optional [n_mb]: FNV-1a of the 460 CABAC context states after each macroblock was written */
+    int dbg_mb; uint8_t *dbg_state;  /* optional: the 460 states after macroblock dbg_mb */
+    int dbg_rd_mb, dbg_rd_n; const int32_t *dbg_rd_in; int32_t *dbg_rd_out;   /* optional: RD cost of given candidates at one macroblock */
 } refh_t;
 
 static void refh_log(void *p, int level, const char *fmt, va_list ap) { (void)p; if (level <= X264_LOG_WARNING) vfprintf(stderr, fmt, ap); }
@@ -56,7 +75,7 @@ static void refh_bind_cmp(x264_t *h)
  * would hold after x264_validate_parameters (encoder.c:342-613) for a CQP, 1-ref,
  * no-B-frame, progressive encode: the caller passes mv_range (level-derived there). */
 void *refh_open(int width, int height, int qp, int me_method, int me_range, int subme,
-                int mv_range, int b_cabac, int embed, int inter_flags)
+                int mv_range, int b_cabac, int embed, int inter_flags, int psy_rd_fix8, int chroma_qp_offset)
 {
     if (width % 16 || height % 16) return NULL;
     int mb_w = width / 16, mb_h = height / 16;
@@ -83,8 +102,11 @@ void *refh_open(int width, int height, int qp, int me_method, int me_range, int 
     h->param.analyse.inter = inter_flags >= 0 ? (unsigned)inter_flags
                            : (X264_ANALYSE_I4x4 | X264_ANALYSE_PSUB16x16 | X264_ANALYSE_BSUB16x16); /* encoder.c:495-502 */
     h->param.analyse.intra = X264_ANALYSE_I4x4;
-    if (subme < 6) h->param.analyse.f_psy_rd = 0;   /* encoder.c:513-514 */
-    h->mb.i_psy_rd = 0; h->mb.i_psy_trellis = 0;
+    /* encoder.c:511-522: psy-RD only from subme 6 on; the caller passes the chroma QP offset the reference would hold
+     * after x264_validate_parameters (psy-RD lowers it by 1 or 2) */
+    h->param.analyse.f_psy_rd = subme < 6 ? 0 : psy_rd_fix8 / 256.0f;
+    h->mb.i_psy_rd = subme < 6 ? 0 : psy_rd_fix8; h->mb.i_psy_trellis = 0;
+    h->param.analyse.i_chroma_qp_offset = chroma_qp_offset;
     h->param.i_bframe_adaptive = X264_B_ADAPT_NONE; /* encoder.c:464-465 */
     h->param.eparam.iEmRate = embed ? 0.5 : 0;
 
@@ -92,7 +114,7 @@ void *refh_open(int width, int height, int qp, int me_method, int me_range, int 
     h->pps = &h->pps_array[0];
     h->sps->i_mb_width = mb_w; h->sps->i_mb_height = mb_h;
     h->sps->b_frame_mbs_only = 1;
-    h->pps->i_chroma_qp_index_offset = 0;
+    h->pps->i_chroma_qp_index_offset = chroma_qp_offset;      /* x264_pps_init, encoder/set.c */
     h->pps->i_cqm_preset = X264_CQM_FLAT;
     for (int i = 0; i < 6; i++) h->pps->scaling_list[i] = x264_cqm_flat16;
     if (x264_cqm_init(h) < 0) return NULL;
@@ -187,6 +209,70 @@ void refh_get_ref_planes(void *ctx, uint8_t *out4 /* 4 * stride*(lines+64) */, u
     if (integral && f->integral) memcpy(integral, f->buffer[3], sz * sizeof(uint16_t));
 }
 
+/* What x264_slice_write does around every macroblock besides analyse / encode (the harness replaces only that driver):
+ * at the start of a macroblock row x264_fdec_filter_row (encoder.c:1019-1030) keeps the last, still unfiltered line of the
+ * row above for intra prediction; after x264_macroblock_encode the macroblock goes through the entropy coder
+ * (encoder.c:1900-1927), which adapts the CABAC context states (and, for CAVLC, leaves the coefficient counts in the
+ * non-zero cache) that the RD mode decision of the following macroblocks reads (--subme >= 6, encoder/rdo.c:139-171). */
+static void refh_row_start(x264_t *h, int mb_y)
+{
+    if (mb_y <= 0) return;
+    for (int i = 0; i < 3; i++)
+        memcpy(h->mb.intra_border_backup[0][i], h->fdec->plane[i] + ((mb_y * 16 >> !!i) - 1) * h->fdec->i_stride[i], h->sps->i_mb_width * 16 >> !!i);
+}
+static void refh_entropy_write(refh_t *c, int mb_xy, int *i_skip)
+{
+    x264_t *h = c->h;
+    if (h->param.b_cabac) {
+        if (mb_xy > h->sh.i_first_mb) x264_cabac_encode_terminal(&h->cabac);
+        if (IS_SKIP(h->mb.i_type)) x264_cabac_mb_skip(h, 1);
+        else { x264_cabac_mb_skip(h, 0); x264_macroblock_write_cabac(h, &h->cabac); }
+        if (h->cabac.p > h->cabac.p_end - 4096) x264_cabac_encode_init(&h->cabac, h->out.p_bitstream, h->out.p_bitstream + h->out.i_bitstream);
+        if (c->dbg_state_hash) {
+            uint32_t hsh = 2166136261u;
+            for (int i = 0; i < 460; i++) hsh = (hsh ^ h->cabac.state[i]) * 16777619u;
+            c->dbg_state_hash[mb_xy] = hsh;
+        }
+        if (c->dbg_state && mb_xy == c->dbg_mb) memcpy(c->dbg_state, h->cabac.state, 460);
+    } else {
+        if (IS_SKIP(h->mb.i_type)) (*i_skip)++;
+        else { bs_write_ue(&h->out.bs, *i_skip); *i_skip = 0; x264_macroblock_write_cavlc(h, &h->out.bs); }
+        if (h->out.bs.p > h->out.bs.p_end - 4096) bs_init(&h->out.bs, h->out.p_bitstream, h->out.i_bitstream);
+    }
+}
+/* diagnostics: x264_rd_cost_mb of n candidates {type, partition, mv[16][2] in block order} = 34 ints each, evaluated at
+ * macroblock mb right after its cache_load (before its real analysis, which rebuilds everything the trial touches) */
+void refh_set_debug_rd(void *ctx, int mb, int n, const int32_t *in, int32_t *out)
+{ refh_t *c = ctx; c->dbg_rd_mb = mb; c->dbg_rd_n = n; c->dbg_rd_in = in; c->dbg_rd_out = out; }
+static void refh_dbg_rd_run(refh_t *c, int qp)
+{
+    x264_t *h = c->h; x264_mb_analysis_t a;
+    x264_mb_analyse_init(h, &a, qp);
+    x264_mb_cache_fenc_satd(h);
+    for (int k = 0; k < c->dbg_rd_n; k++) {
+        const int32_t *in = c->dbg_rd_in + 34 * k;
+        if (in[0] < 0) {        /* intra SATD analysis with i_satd_inter = in[1] */
+            x264_mb_analysis_t b; x264_mb_analyse_init(h, &b, qp);
+            x264_mb_analyse_intra_chroma(h, &b);
+            x264_mb_analyse_intra(h, &b, in[1] - b.i_satd_i8x8chroma);
+            c->dbg_rd_out[4 * k] = b.i_satd_i16x16; c->dbg_rd_out[4 * k + 1] = b.i_satd_i4x4; c->dbg_rd_out[4 * k + 2] = b.i_satd_i8x8chroma; c->dbg_rd_out[4 * k + 3] = b.b_fast_intra;
+            continue;
+        }
+        h->mb.i_type = in[0]; h->mb.i_partition = in[1];
+        for (int i = 0; i < 4; i++) h->mb.i_sub_partition[i] = D_L0_8x8;
+        for (int i = 0; i < 16; i++) {
+            h->mb.cache.ref[0][x264_scan8[i]] = 0;
+            h->mb.cache.mv[0][x264_scan8[i]][0] = in[2 + 2 * i]; h->mb.cache.mv[0][x264_scan8[i]][1] = in[3 + 2 * i];
+        }
+        c->dbg_rd_out[4 * k] = x264_rd_cost_mb(h, a.i_lambda2);
+        c->dbg_rd_out[4 * k + 1] = ssd_mb(h);
+        c->dbg_rd_out[4 * k + 2] = h->mb.i_cbp_luma | h->mb.i_cbp_chroma << 4;
+        c->dbg_rd_out[4 * k + 3] = 0;
+    }
+}
+void refh_set_debug(void *ctx, uint32_t *state_hash, int dump_mb, uint8_t *dump_state)
+{ refh_t *c = ctx; c->dbg_state_hash = state_hash; c->dbg_mb = dump_mb; c->dbg_state = dump_state; }
+
 typedef struct {
     int32_t type, partition, qp;
     uint8_t sub_partition[4];
@@ -228,15 +314,20 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
     x264_cabac_encode_init(&h->cabac, h->out.p_bitstream, h->out.p_bitstream + h->out.i_bitstream);
     h->mb.i_last_qp = qp; h->mb.i_last_dqp = 0;
 
+    bs_init(&h->out.bs, h->out.p_bitstream, h->out.i_bitstream);
+    int i_skip = 0;
     for (int my = 0; my < c->mb_h; my++)
         for (int mx = 0; mx < c->mb_w; mx++) {
             int mb_xy = my * c->mb_w + mx;
+            if (mx == 0) refh_row_start(h, my);
             x264_macroblock_cache_load(h, mx, my);
+            if (c->dbg_rd_out && mb_xy == c->dbg_rd_mb) refh_dbg_rd_run(c, qp);
             refh_mb_t *o = &out[mb_xy];
             memset(o, 0, sizeof(*o));
             o->pskip_mv[0] = h->mb.cache.pskip_mv[0]; o->pskip_mv[1] = h->mb.cache.pskip_mv[1];
             x264_macroblock_analyse(h);
             x264_macroblock_encode(h);
+            refh_entropy_write(c, mb_xy, &i_skip);
             o->type = h->mb.i_type; o->partition = h->mb.i_partition; o->qp = h->mb.i_qp;
             /* i_sub_partition is stale outside P_8x8 and mvr is never written for an early P_SKIP
              * (analyse.c:1170-1177 returns first): report neutral values for those don't-cares */
@@ -285,12 +376,16 @@ int refh_pass2_pframe(void *ctx, int qp, const int8_t *flips, int n_flips, refh_
     x264_cabac_context_init(&h->cabac, h->sh.i_type, h->sh.i_qp, 0);
     x264_cabac_encode_init(&h->cabac, h->out.p_bitstream, h->out.p_bitstream + h->out.i_bitstream);
     h->mb.i_last_qp = qp; h->mb.i_last_dqp = 0;
+    bs_init(&h->out.bs, h->out.p_bitstream, h->out.i_bitstream);
+    int i_skip = 0;
     for (int my = 0; my < c->mb_h; my++)
         for (int mx = 0; mx < c->mb_w; mx++) {
             int mb_xy = my * c->mb_w + mx;
+            if (mx == 0) refh_row_start(h, my);
             x264_macroblock_cache_load(h, mx, my);
             x264_macroblock_analyse(h);
             x264_macroblock_encode(h);
+            refh_entropy_write(c, mb_xy, &i_skip);
             refh_mb_t *o = &out[mb_xy];
             memset(o, 0, sizeof(*o));
             o->type = h->mb.i_type; o->partition = h->mb.i_partition; o->qp = h->mb.i_qp;
@@ -322,6 +417,14 @@ int refh_pass2_pframe(void *ctx, int qp, const int8_t *flips, int n_flips, refh_
 int refh_sad(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.sad[i_pixel](a, sa, b, sb); }
 int refh_satd(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.satd[i_pixel](a, sa, b, sb); }
 int refh_ssd(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.ssd[i_pixel](a, sa, b, sb); }
+/* intra prediction into a stride-32 buffer that holds the neighbours (common/predict.c): kind 0 = 16x16, 1 = 8x8 chroma, 2 = 4x4 */
+void refh_predict(void *ctx, int kind, int mode, uint8_t *dst)
+{
+    x264_t *h = ((refh_t *)ctx)->h;
+    if (kind == 0) h->predict_16x16[mode](dst); else if (kind == 1) h->predict_8x8c[mode](dst); else h->predict_4x4[mode](dst);
+}
+void refh_hadamard_ac(void *ctx, int i_pixel, uint8_t *pix, int stride, uint32_t out[2])
+{ uint64_t v = ((refh_t *)ctx)->h->pixf.hadamard_ac[i_pixel](pix, stride); out[0] = (uint32_t)v; out[1] = (uint32_t)(v >> 32); }
 int refh_sa8d(void *ctx, int i_pixel, uint8_t *a, int sa, uint8_t *b, int sb) { return ((refh_t *)ctx)->h->pixf.sa8d[i_pixel](a, sa, b, sb); }
 void refh_mc_luma(void *ctx, uint8_t *dst, int ds, uint8_t *src4[4], int ss, int mvx, int mvy, int w, int hgt)
 { ((refh_t *)ctx)->h->mc.mc_luma(dst, ds, src4, ss, mvx, mvy, w, hgt); }

@@ -46,7 +46,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(LIB_PATH)
         _lib.refh_open.restype = C.c_void_p
-        _lib.refh_open.argtypes = [C.c_int] * 10
+        _lib.refh_open.argtypes = [C.c_int] * 12
     return _lib
 
 
@@ -56,14 +56,28 @@ def _p(a):
 
 class Ref:
     def __init__(self, width, height, qp=26, me="hex", me_range=16, subme=5, mv_range=128,
-                 cabac=1, embed=1, inter_flags=-1):
+                 cabac=1, embed=1, inter_flags=-1, psy_rd=1.0, chroma_qp_offset=None):
+        """psy_rd: --psy-rd strength (only acts from subme 6 on, encoder.c:513); chroma_qp_offset: the value the reference
+        holds after x264_validate_parameters (default: 0, lowered by 2 when psy-RD is active, encoder.c:520-521)"""
+        psy_fix8 = int(psy_rd * 256 + 0.5) if subme >= 6 else 0
+        if chroma_qp_offset is None:
+            chroma_qp_offset = 0 if not psy_fix8 else (-1 if psy_rd < 0.25 else -2)
+        self.psy_fix8, self.chroma_qp_offset = psy_fix8, chroma_qp_offset
         self.w, self.h = width, height
         self.mb_w, self.mb_h = width // 16, height // 16
         self.qp = qp
         self.ctx = C.c_void_p(lib().refh_open(width, height, qp, ME[me], me_range, subme,
-                                               mv_range, cabac, embed, inter_flags))
+                                               mv_range, cabac, embed, inter_flags, psy_fix8, chroma_qp_offset))
+        self._dbg = None
         if not self.ctx:
             raise RuntimeError("refh_open failed (size > 396 MBs?)")
+
+    def debug_state_hash(self, dump_mb=-1):
+        """ask for the FNV-1a hash of the CABAC context states after every macroblock of the following analyse calls"""
+        self._dbg = np.zeros(self.mb_w * self.mb_h, np.uint32)
+        self._dump = np.zeros(460, np.uint8)
+        lib().refh_set_debug(self.ctx, _p(self._dbg), dump_mb, _p(self._dump))
+        return self._dbg
 
     def set_ref(self, y, u, v, prev_mv=None, prev_ref=None, prev_type=None):
         y, u, v = [np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v)]

@@ -7,6 +7,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ANALYSIS_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3",
                      "qcif_tesa_subme5_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
+# --subme 6 / 7 (RD mode decision): CABAC and CAVLC sizes, psy-RD on / off, embedding off (no P_8x8 then, analyse.c:2841)
+RD_FIXTURES = ["qcif_hex_subme6", "qcif_umh_subme7_cavlc", "qcif_dia_subme6_nopsy_noisy", "qcif_esa_subme6_noembed", "cif_umh_subme7"]
+
+
+def fixture_params(g, make_params, **over):
+    """the parameter block a fixture was minted with (older fixtures predate the RD fields)"""
+    kw = dict(me=int(g["me"]), subme=int(g["subme"]), mv_range=int(g["mv_range"]), inter=int(g["inter"]) | 1,
+              me_range=int(g["me_range"]), tscale=256)
+    if "cabac" in g:
+        kw.update(cabac=int(g["cabac"]), psy_rd=int(g["psy_rd_fix8"]) / 256.0, chroma_qp_offset=int(g["chroma_qp_offset"]))
+    kw.update(over)
+    return make_params(int(g["width"]), int(g["height"]), **kw)
+
+
 # reference-harness field -> pcamv_mb_t field
 FIELD_MAP = (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"),
              ("ref", "ref"), ("mv", "mv"), ("mv_stego", "mv_stego"), ("stego_cost", "inter_stego_cost"),

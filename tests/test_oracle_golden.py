@@ -119,13 +119,42 @@ def test_single_motion_searches_match_reference(prim):
         o.close()
 
 
-@pytest.mark.parametrize("name", helpers.ANALYSIS_FIXTURES)
+@pytest.fixture(scope="module")
+def prim_rd():
+    return helpers.load("primitives_rd")
+
+
+def test_intra_prediction_matches_reference(prim_rd):
+    """common/predict.c: every 16x16 / chroma 8x8 / 4x4 mode incl. the DC variants, neighbours in place"""
+    import ctypes as C
+    L = orc.lib()
+    for buf, exp, (kind, mode) in zip(prim_rd["ipred_in"], prim_rd["ipred_out"], prim_rd["ipred_kind"]):
+        b = buf.copy()
+        L.orc_predict(int(kind), int(mode), C.c_void_p(b.ctypes.data + 8 * 32 + 8))
+        assert np.array_equal(b, exp), (int(kind), int(mode))
+
+
+def test_sa8d_and_hadamard_ac_match_reference(prim_rd):
+    """common/pixel.c:256-358 (psy-RD's complexity measures) incl. checkasm's overflow patterns"""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_hadamard_ac.restype = C.c_uint64
+    for i, (pix, other) in enumerate(zip(prim_rd["hac_pix"], prim_rd["hac_other"])):
+        pix, other = np.ascontiguousarray(pix), np.ascontiguousarray(other)
+        for ip in range(4):
+            v = L.orc_hadamard_ac(ip, C.c_void_p(pix.ctypes.data), 32)
+            assert (v & 0xffffffff, v >> 32) == tuple(int(x) for x in prim_rd["hac_res"][i, ip]), (i, ip)
+        for k, ip in enumerate((0, 3)):
+            assert L.orc_sa8d(ip, C.c_void_p(pix.ctypes.data), 32, C.c_void_p(other.ctypes.data), 16) == int(prim_rd["sa8d_res"][i, k])
+
+
+@pytest.mark.parametrize("name", helpers.ANALYSIS_FIXTURES + helpers.RD_FIXTURES)
 def test_pframe_analysis_matches_reference(name):
     g = helpers.load(name)
     W, H = int(g["width"]), int(g["height"])
-    p = orc.make_params(W, H, me=int(g["me"]), subme=int(g["subme"]), mv_range=int(g["mv_range"]),
-                        inter=int(g["inter"]), me_range=int(g["me_range"]), tscale=256)
-    o = orc.Oracle(p)
+    embed = int(g["embed"]) if "embed" in g else 1
+    o = orc.Oracle(helpers.fixture_params(g, orc.make_params))
+    hashes = o.debug_state_hash()
     for t in range(1, int(g["frames"]) + 1):
         prev = (g[f"f{t}_prev_mv"], g[f"f{t}_prev_ref"]) if f"f{t}_prev_mv" in g else (None, None)
         o.set_ref(g[f"f{t}_ref_y"], g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev)
@@ -136,10 +165,12 @@ def test_pframe_analysis_matches_reference(name):
         if f"f{t}_integral_sha" in g:
             integ = o.ref_integral()
             assert sha(integ[24:H + 32 - 8, 24:W + 32 - 8]) == str(g[f"f{t}_integral_sha"][0])
-        mbs, rec = o.analyse_pframe(int(g["qp"]), 1)
+        mbs, rec = o.analyse_pframe(int(g["qp"]), embed)
         helpers.compare_records(g[f"f{t}_mbs"], mbs, f"{name} frame {t}")
         for k, nm in enumerate("yuv"):
             assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
+        if f"f{t}_cabac_state_hash" in g:     # the entropy coder's context states after every macroblock
+            assert np.array_equal(hashes, g[f"f{t}_cabac_state_hash"]), f"{name} frame {t}: CABAC context adaptation"
     o.close()
 
 

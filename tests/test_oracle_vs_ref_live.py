@@ -52,3 +52,44 @@ def test_oracle_matches_reference_code(cfg):
         prev = helpers.mv_field(mbs_o["mv"], W // 16, H // 16)
         ref = rec_o
     o.close()
+
+
+# --subme 6 / 7: RD mode decision with the size-only CABAC / CAVLC coders, psy-RD, intra SATD thresholds
+LIVE_RD = [
+    # (W, H, me, subme, qp, seed, static_cols, cabac, psy_rd, noise, embed)
+    (176, 144, "hex", 6, 12, 51, 32, 1, 1.0, 40, 1),
+    (176, 144, "hex", 7, 20, 52, 32, 0, 1.0, 40, 1),
+    (176, 144, "umh", 6, 38, 53, 0, 1, 2.0, 25, 1),
+    (176, 144, "dia", 7, 45, 54, 48, 0, 0.1, 6, 1),
+    (176, 144, "esa", 6, 30, 55, 16, 1, 0.0, 40, 0),
+    (352, 288, "hex", 6, 28, 56, 64, 0, 1.0, 12, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", LIVE_RD, ids=[f"{c[2]}_s{c[3]}_qp{c[4]}_{'cabac' if c[7] else 'cavlc'}_psy{c[8]}_e{c[10]}" for c in LIVE_RD])
+def test_oracle_rd_mode_decision_matches_reference_code(cfg):
+    from pcamv_amd.synth import make_clip
+    W, H, me, subme, qp, seed, static, cabac, psy, noise, embed = cfg
+    clip = make_clip(W, H, 3, seed=seed, static_cols=static, noise=noise)
+    mvr = orc.level_mv_range(W, H)
+    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, embed=embed, inter_flags=0x111, cabac=cabac, psy_rd=psy)
+    o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=0x11, cabac=cabac, psy_rd=psy))
+    hr, ho = r.debug_state_hash(), o.debug_state_hash()
+    ref, prev = clip[0], (None, None)
+    for t in (1, 2):
+        if prev[0] is None:
+            r.set_ref(*ref)
+        else:
+            r.set_ref(*ref, prev_mv=prev[0], prev_ref=prev[1])
+        r.set_fenc(*clip[t])
+        o.set_ref(*ref, *prev); o.set_fenc(*clip[t])
+        mbs_r, rec_r = r.analyse_pframe()
+        mbs_o, rec_o = o.analyse_pframe(qp, embed)
+        helpers.compare_records(mbs_r, mbs_o, f"{cfg} frame {t}")
+        for a, b in zip(rec_r, rec_o):
+            assert np.array_equal(a, b), f"{cfg} frame {t}: reconstruction"
+        if cabac:
+            assert np.array_equal(hr, ho), f"{cfg} frame {t}: CABAC context states"
+        prev = helpers.mv_field(mbs_o["mv"], W // 16, H // 16)
+        ref = rec_o
+    o.close()
