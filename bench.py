@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088, help="coded height (1080 rounded up to 16)")
     ap.add_argument("--me", default="umh")
-    ap.add_argument("--subme", type=int, default=5)
+    ap.add_argument("--subme", type=int, default=7)
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--emrate", type=float, default=0.5)
     ap.add_argument("--open-loop", action="store_true", help="pass 1 only: no pass 2 / loop filter, the reference is the previous source frame")
@@ -120,7 +120,7 @@ def main():
     prof = None
     if os.environ.get("PCAMV_PROF_DUMP") == "1":      # diagnostics build of the library (-DPCAMV_PROF): wave cycles per phase
         import ctypes
-        prof = (ctypes.c_ulonglong * 16)()
+        prof = (ctypes.c_ulonglong * 24)()
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 1)
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -169,7 +169,9 @@ def main():
         nmb = args.gops * n_mb * args.steps
         names = ["pop+wait", "search", "publish", "reconstruct+RCA", "whole iteration", "-", "16x16 (+skip probe)", "8x8", "sub8x8 + 16x8 + 8x16",
                  "final qpel refine", "reconstruction", "neighbour load", "record store",
-                 "pop: ticket (or pass 2: pop+wait)", "pop: queue entry wait (or pass 2: work)", "pop: descriptor load (or pass 2: publish)"]
+                 "pop: ticket (or pass 2: pop+wait)", "pop: queue entry wait (or pass 2: work)", "pop: descriptor load (or pass 2: publish)",
+                 "rd: intra SATD analysis", "rd: x264_mb_analyse_p_rd", "rd trial: predict + transform", "rd trial: ssd + psy", "rd trial: cabac header",
+                 "rd trial: cabac residual", "rd: final encode + entropy commit", "-"]
         print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
     # dominant kernel: average duration of one launch, HIP events on its own stream
     dom = batch.dominant_kernel()
@@ -239,7 +241,8 @@ def main():
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
-        op = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256)
+        op = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac)
+        assert (op.i_psy_rd, op.i_chroma_qp_offset) == (p.i_psy_rd, p.i_chroma_qp_offset)
         o = orc.Oracle(op)
         tcpu = 0.0
         prev = (None, None)

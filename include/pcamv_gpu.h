@@ -216,6 +216,11 @@ int pcamv_gpu_block_costs(pcamv_ctx_t *ctx, int qp, int n, const int32_t *req, i
 int pcamv_gpu_trace_mb(pcamv_ctx_t *ctx, int mb);
 int pcamv_gpu_trace_fetch(pcamv_ctx_t *ctx, int32_t *out);
 
+/* Diagnostics for the parity tests of the RD mode decision (--subme >= 6 with CABAC): FNV-1a of the 460 context states
+ * after every macroblock of the following analyses; out holds mb_count words. */
+int pcamv_gpu_debug_state_hash(pcamv_ctx_t *ctx, int enable);
+int pcamv_gpu_debug_state_hash_fetch(pcamv_ctx_t *ctx, uint32_t *out);
+
 int pcamv_gpu_abi_version(void);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ def build(sanitize=False):
     return LIB
 
 
-def analyse_pframe(orc_mod, params, qp, embed, fenc, ref_planes4, ref_u, ref_v, prev_mv=None, prev_ref=None, diag=1, trace_mb=-1):
+def analyse_pframe(orc_mod, params, qp, embed, fenc, ref_planes4, ref_u, ref_v, prev_mv=None, prev_ref=None, diag=1, trace_mb=-1, state_hash=None):
     lib = C.CDLL(build())
     W, H = params.i_width, params.i_height
     n_mb = (W // 16) * (H // 16)
@@ -42,10 +42,12 @@ def analyse_pframe(orc_mod, params, qp, embed, fenc, ref_planes4, ref_u, ref_v, 
     P = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
     if prev_mv is not None:
         prev_mv = np.ascontiguousarray(prev_mv, np.int16); prev_ref = np.ascontiguousarray(prev_ref, np.int8)
+    if state_hash is not None:
+        assert state_hash.dtype == np.uint32 and state_hash.flags.c_contiguous
     trace = np.zeros(1 + 8 * 4000, np.int32)
     lib.emu_analyse_pframe(C.byref(params), qp, embed, P(f[0]), P(f[1]), P(f[2]), P(luma), P(cu), P(cv),
                            P(prev_mv), P(prev_ref), P(mbs), P(rec[0]), P(rec[1]), P(rec[2]), diag,
-                           P(trace) if trace_mb >= 0 else None, trace_mb)
+                           P(trace) if trace_mb >= 0 else None, trace_mb, P(state_hash))
     if trace_mb >= 0:
         return mbs, rec, trace[1:1 + 8 * trace[0]].reshape(-1, 8)
     return mbs, rec

@@ -15,7 +15,7 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
                                   const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                                   uint8_t *luma4, uint8_t *cu, uint8_t *cv,
                                   const int16_t *prev_mv, const int8_t *prev_ref,
-                                  pcamv_mb_t *out, uint8_t *ry, uint8_t *ru, uint8_t *rv, int diag_order, int *trace, int trace_mb)
+                                  pcamv_mb_t *out, uint8_t *ry, uint8_t *ru, uint8_t *rv, int diag_order, int *trace, int trace_mb, uint32_t *dbg_hash)
 {
     FrameDev F = {};
     pcamv_frame_set_params(&F, p);
@@ -34,22 +34,33 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     F.mvp_aux = (int16_t *)calloc((size_t)F.n_mb * 32, 2);
     F.prev_mv = prev_mv; F.prev_ref = prev_ref; F.have_prev = prev_mv != NULL && p->i_tscale != 0;
     F.rec_mb = out;
+    /* --subme >= 6 */
+    F.ref_is_inter = prev_mv != NULL;
+    F.nb_nz = (uint8_t *)calloc((size_t)F.n_mb, 16); F.nb_cbp = (int16_t *)calloc((size_t)F.n_mb, 2); F.nb_mvd = (int16_t *)calloc((size_t)F.n_mb * 16, 2);
+    uint8_t cab[464], cab_init[464]; uint32_t cab_tab[256];
+    pcamv_build_cabac_init(qp, cab_init); pcamv_build_cabac_tab(cab_tab);
+    F.cabac = cab; F.cabac_init = cab_init; F.cabac_tab = cab_tab; F.dbg_hash = dbg_hash;
     int16_t *cost = (int16_t *)malloc(PCAMV_COST_MV_LEN * sizeof(int16_t));
     pcamv_build_cost_mv(qp, cost);
     F.cost_mv = cost + PCAMV_COST_MV_CENTRE;
     MBLocal *L = (MBLocal *)malloc(sizeof(MBLocal));
     Analysis *a = (Analysis *)malloc(sizeof(Analysis));
+    if (diag_order == 3) {  /* raster order, fused: what the dataflow schedule does when the entropy coder is CABAC (one chain per frame) */
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) { mbk_search<3>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); }
+        free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux); free(F.nb_nz); free(F.nb_cbp); free(F.nb_mvd);
+        return 0;
+    }
     if (diag_order == 2) {  /* dataflow schedule: search, then RCA + reconstruction of the same macroblock, in a dependency-legal order */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<1>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1); } }
+            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<3>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); } }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
         return 0;
     }
     if (diag_order) {       /* the order the GPU uses: anti-diagonals x + 2y = d */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search<1>(F, L, a, x, y); }
+            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search<3>(F, L, a, x, y); }
     } else
-        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) mbk_search<1>(F, L, a, x, y);
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) mbk_search<3>(F, L, a, x, y);
     if (embed)
         for (int xy = F.n_mb - 1; xy >= 0; xy--) for (int k = 15; k >= 0; k--) mbk_rca(F, L, a, xy, k);
     for (int xy = 0; xy < F.n_mb; xy++) mbk_encode(F, L, a, xy);

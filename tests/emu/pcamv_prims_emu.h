@@ -8,7 +8,11 @@
 #include <string.h>
 #include <stddef.h>
 #include "pcamv_common.h"
+#include "pcamv_entropy_tables.h"
 
+static inline void cb_dec(MBLocal *L, uint8_t *S, int ctx, int b, int *bits);
+static inline int size_ue_of(unsigned v);
+static inline void predict_mv(MBLocal *L, int idx, int width, int mvp[2]);
 /* the reference's own tables (common/mc.c:194-200 hpel_ref0/1, dct.h zigzag, quant.c:203 decimate table) for the scalar restatement */
 static const int hpel_ref0_tab[16] = {0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1};
 static const int hpel_ref1_tab[16] = {0, 0, 0, 0, 2, 2, 3, 2, 2, 2, 3, 2, 2, 2, 3, 2};
@@ -275,9 +279,31 @@ static inline void prim_add_idct(const FrameDev &F, MBLocal *L, unsigned keep, i
 }
 /* transform stage of x264_macroblock_encode for an inter macroblock (encoder/macroblock.c:277-372, 696-753),
  * scalar restatement with the reference's own loops (the GPU primitive does this lane-parallel) */
-static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
+static inline void prim_mb_transform(const FrameDev &F, MBLocal *L, int lv = 0)
 {
     prim_residual(F, L, 1, 1);
+    int16_t lvq[24][16];           /* quantised levels in scan order: requantise from the forward transform (prim_residual keeps only the dequantised ones) */
+    if (lv)
+        for (int b = 0; b < 24; b++) {
+            int is_l = b < 16, ch = (b - 16) >> 2, ci = (b - 16) & 3;
+            int px = is_l ? 4 * blk_x_of(b) : ch * 8 + (ci & 1) * 4, py = is_l ? 4 * blk_y_of(b) : 16 + (ci >> 1) * 4;
+            int d[4][4], t[4][4], c[16];
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y][x] = L->fenc[(py + y) * 16 + px + x] - L->pred[(py + y) * 16 + px + x];
+            for (int i = 0; i < 4; i++) {
+                int s03 = d[i][0] + d[i][3], s12 = d[i][1] + d[i][2], d03 = d[i][0] - d[i][3], d12 = d[i][1] - d[i][2];
+                t[0][i] = s03 + s12; t[1][i] = 2 * d03 + d12; t[2][i] = s03 - s12; t[3][i] = d03 - 2 * d12;
+            }
+            for (int i = 0; i < 4; i++) {
+                int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+                c[i * 4] = s03 + s12; c[i * 4 + 1] = 2 * d03 + d12; c[i * 4 + 2] = s03 - s12; c[i * 4 + 3] = d03 - 2 * d12;
+            }
+            if (!is_l) c[0] = 0;
+            for (int i = 0; i < 16; i++) {
+                int cls = (i & 1) + ((i >> 2) & 1), mf = F.q_mf[is_l ? 0 : 1][cls], bias = F.q_bias[is_l ? 0 : 1][cls], v = c[i];
+                c[i] = v > 0 ? ((bias + v) * mf >> 16) : -((bias - v) * mf >> 16);
+            }
+            for (int k = 0; k < 16; k++) lvq[b][k] = (int16_t)c[zz4_tab[k]];
+        }
     /* luma 8x8 / MB decimation (encoder/macroblock.c:696-753) */
     unsigned keep = 0; int cbp = 0, decimate_mb = 0;
     for (int i8 = 0; i8 < 4; i8++) {
@@ -296,7 +322,7 @@ static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
     L->nnz_mask = 0;
     for (int idx = 0; idx < 16; idx++) if (((keep >> idx) & 1) && L->blk_nz[idx]) L->nnz_mask |= 1 << idx;
     /* chroma (encoder/macroblock.c:277-372) */
-    int cmode[2], any_ac = 0;
+    int cmode[2], any_ac = 0, dcl[2][4] = {{0}}, dcnz[2] = {0, 0};
     for (int ch = 0; ch < 2; ch++) {
         int score = 0, nz_ac = 0, nz_dc = 0;
         for (int i = 0; i < 4; i++) if (L->blk_nz[16 + ch * 4 + i]) { nz_ac = 1; if (F.b_dct_decimate) score += L->blk_score[16 + ch * 4 + i]; }
@@ -307,6 +333,8 @@ static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
               dc[k] = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
               nz_dc |= dc[k];
           } }
+        for (int k = 0; k < 4; k++) dcl[ch][k] = dc[k];
+        dcnz[ch] = nz_dc != 0;
         int d0 = dc[0] + dc[1], d1 = dc[2] + dc[3], d2 = dc[0] - dc[1], d3 = dc[2] - dc[3];
         int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
         if (qbits > 0) { dmf <<= qbits; qbits = 0; }
@@ -324,8 +352,19 @@ static inline void prim_mb_transform(const FrameDev &F, MBLocal *L)
             }
         }
     }
-    L->cbp_chroma = any_ac ? 2 : 0;
+    L->cbp_chroma = any_ac ? 2 : (dcnz[0] | dcnz[1]) ? 1 : 0;       /* encoder/macroblock.c:364-372 */
     prim_add_idct(F, L, keep, cmode[0], cmode[1]);
+    if (lv) {
+        for (int b = 0; b < 16; b++) L->nzc[scan8_all_of(b)] = (uint8_t)((L->nnz_mask >> b) & 1);
+        for (int b = 16; b < 24; b++) L->nzc[scan8_all_of(b)] = (uint8_t)(cmode[(b - 16) >> 2] == 2 && L->blk_nz[b]);
+        L->nzc[scan8_all_of(24)] = 0;
+        for (int ch = 0; ch < 2; ch++) {
+            L->nzc[scan8_all_of(25 + ch)] = (uint8_t)dcnz[ch];
+            /* zigzag_scan_2x2_dc (encoder/macroblock.c:31-38): d[0][0], d[1][0], d[0][1], d[1][1] */
+            L->cdc[ch][0] = (int16_t)dcl[ch][0]; L->cdc[ch][1] = (int16_t)dcl[ch][2]; L->cdc[ch][2] = (int16_t)dcl[ch][1]; L->cdc[ch][3] = (int16_t)dcl[ch][3];
+        }
+        for (int b = 0; b < 24; b++) for (int k = 0; k < 16; k++) L->coef[b][k] = lvq[b][k];
+    }
 }
 /* the four-at-once RCA re-encodes, scalar: one prediction / transform after the other */
 static inline void prim_predict_win16(const FrameDev &F, MBLocal *L, int j, int mvx, int mvy)
@@ -343,11 +382,363 @@ static inline void prim_mb_transform4(const FrameDev &F, MBLocal *L)
     memcpy(keep, L->pred, sizeof(keep));
     for (int j = 0; j < 4; j++) {
         memcpy(L->pred, in[j], sizeof(keep));
-        prim_mb_transform(F, L);
+        prim_mb_transform(F, L, 0);
         memcpy(in[j], L->pred, sizeof(keep));
     }
     memcpy(L->pred, keep, sizeof(keep));
     memcpy(L->pred4, in, sizeof(in));
+}
+
+/* ------------------------------------------------------------------ --subme >= 6 (scalar stand-ins of the RD primitives) */
+static inline void prim_rd_load(const FrameDev &F, MBLocal *L)
+{
+    static const uint8_t top_pos[8] = {4, 5, 6, 7, 1, 2, 1 + 3 * 8, 2 + 3 * 8}, left_pos[8] = {3 + 8, 3 + 16, 3 + 24, 3 + 32, 0 + 8, 0 + 16, 0 + 32, 0 + 40};
+    const int xy = L->mb_xy, top = xy - F.mb_w;
+    memset(L->nzc, 0, sizeof(L->nzc)); memset(L->cmvd, 0, sizeof(L->cmvd)); memset(L->i4mode, -1, sizeof(L->i4mode));
+    for (int k = 0; k < 8; k++) {
+        L->nzc[top_pos[k]] = (L->neighbour & NB_TOP) ? F.nb_nz[top * 16 + k] : 0x80;
+        L->nzc[left_pos[k]] = (L->neighbour & NB_LEFT) ? F.nb_nz[(xy - 1) * 16 + 8 + k] : 0x80;
+    }
+    L->cbp_top = (L->neighbour & NB_TOP) ? F.nb_cbp[top] : -1;
+    L->cbp_left = (L->neighbour & NB_LEFT) ? F.nb_cbp[xy - 1] : -1;
+    for (int k = 0; k < 4; k++) {
+        if (L->neighbour & NB_TOP) { L->cmvd[SCAN8_0 - 8 + k][0] = F.nb_mvd[(top * 8 + k) * 2]; L->cmvd[SCAN8_0 - 8 + k][1] = F.nb_mvd[(top * 8 + k) * 2 + 1]; L->i4mode[SCAN8_0 - 8 + k] = 2; }
+        if (L->neighbour & NB_LEFT) { L->cmvd[SCAN8_0 - 1 + 8 * k][0] = F.nb_mvd[((xy - 1) * 8 + 4 + k) * 2]; L->cmvd[SCAN8_0 - 1 + 8 * k][1] = F.nb_mvd[((xy - 1) * 8 + 4 + k) * 2 + 1]; L->i4mode[SCAN8_0 - 1 + 8 * k] = 2; }
+    }
+    for (int c = 0; c < 3; c++) {
+        const int w = c ? 8 : 16, pw = c ? F.w / 2 : F.w, x0 = L->mb_x * w, y0 = L->mb_y * w;
+        for (int x = -1; x < w + w / 2; x++) L->ib_top[c][4 + x] = L->mb_y > 0 ? F.rec[c][(size_t)(y0 - 1) * pw + clip3i(x0 + x, 0, pw - 1)] : 0;
+        for (int y = 0; y < w; y++) L->ib_left[c][y] = L->mb_x > 0 ? F.rec[c][(size_t)(y0 + y) * pw + x0 - 1] : 0;
+    }
+    if (F.b_cabac) {
+        memcpy(L_CAB(L, 0), xy == 0 ? F.cabac_init : F.cabac, 464);
+        memcpy(L_CTAB(L), F.cabac_tab, 1024);
+    }
+    L->b_fast_intra = xy > 4 && F.ref_is_inter;          /* analyse.c:363-378 */
+}
+#define EF1(a, b) (((a) + (b) + 1) >> 1)
+#define EF2(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
+/* H.264 8.3.1.2 / 8.3.3 / 8.3.4 from explicit neighbour arrays: top[-1] is the top-left sample */
+static inline void emu_pred_plane(uint8_t *dst, int ds, int n, const uint8_t *top, const uint8_t *left)
+{
+    const int h = n / 2;
+    int H = 0, V = 0;
+    for (int i = 1; i <= h; i++) { H += i * (top[h - 1 + i] - top[h - 1 - i]); V += i * ((int)left[h - 1 + i] - (h - 1 - i < 0 ? top[-1] : left[h - 1 - i])); }
+    const int a = 16 * (left[n - 1] + top[n - 1]), b = n == 16 ? (5 * H + 32) >> 6 : (17 * H + 16) >> 5, c = n == 16 ? (5 * V + 32) >> 6 : (17 * V + 16) >> 5;
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) dst[y * ds + x] = (uint8_t)clip3i((a + b * (x - (h - 1)) + c * (y - (h - 1)) + 16) >> 5, 0, 255);
+}
+static inline void prim_intra16_satd(const FrameDev &F, MBLocal *L, int avail)
+{
+    const uint8_t *top = L->ib_top[0] + 4, *left = L->ib_left[0];
+    const int satd = F.subme > 1;
+    for (int m = 0; m < 4; m++) {
+        uint8_t p[16 * 16];
+        const int need = m == 0 ? 2 : m == 1 ? 1 : m == 3 ? 3 : 0;
+        if ((avail & need) != need || (m == 3 && avail != 3)) { L->ccost[m] = PCAMV_COST_MAX; continue; }
+        int st = 0, sl = 0;
+        for (int i = 0; i < 16; i++) { st += top[i]; sl += left[i]; }
+        const int dc = avail == 3 ? (st + sl + 16) >> 5 : avail == 1 ? (sl + 8) >> 4 : avail == 2 ? (st + 8) >> 4 : 128;
+        if (m == 3) emu_pred_plane(p, 16, 16, top, left);
+        else for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) p[y * 16 + x] = (uint8_t)(m == 0 ? top[x] : m == 1 ? left[y] : dc);
+        L->ccost[m] = emu_cmp(16, 16, p, 16, L->fenc, 16, satd);
+    }
+}
+static inline void prim_intra8c_satd(const FrameDev &F, MBLocal *L, int avail)
+{
+    const int satd = F.subme > 1;
+    for (int m = 0; m < 4; m++) {       /* DC, H, V, P */
+        const int need = m == 1 ? 1 : m == 2 ? 2 : m == 3 ? 3 : 0;
+        if ((avail & need) != need) { L->ccost[m] = PCAMV_COST_MAX; continue; }
+        int cost = 0;
+        for (int c = 1; c < 3; c++) {
+            const uint8_t *top = L->ib_top[c] + 4, *left = L->ib_left[c];
+            uint8_t p[8 * 8];
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int i = 0; i < 4; i++) { s0 += top[i]; s1 += top[4 + i]; s2 += left[i]; s3 += left[4 + i]; }
+            if (m == 3) emu_pred_plane(p, 8, 8, top, left);
+            else for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) {
+                int v;
+                if (m == 1) v = left[y]; else if (m == 2) v = top[x];
+                else if (avail == 3) v = (x < 4 && y < 4) ? (s0 + s2 + 4) >> 3 : y < 4 ? (s1 + 2) >> 2 : x < 4 ? (s3 + 2) >> 2 : (s1 + s3 + 4) >> 3;
+                else if (avail == 1) v = y < 4 ? (s2 + 2) >> 2 : (s3 + 2) >> 2;
+                else if (avail == 2) v = x < 4 ? (s0 + 2) >> 2 : (s1 + 2) >> 2;
+                else v = 128;
+                p[y * 8 + x] = (uint8_t)v;
+            }
+            cost += emu_cmp(8, 8, p, 8, L->fenc + 256 + (c - 1) * 8, 16, satd);
+        }
+        L->ccost[m] = cost;
+    }
+}
+static inline void prim_intra4_init(MBLocal *L)
+{
+    for (int x = -1; x < 24; x++) IFD(L, x, -1) = L->ib_top[0][4 + x];
+    for (int y = 0; y < 16; y++) IFD(L, -1, y) = L->ib_left[0][y];
+}
+static inline void emu_pred4(const MBLocal *L, int bx, int by, int mode, uint8_t p[16])
+{
+    int t[8], l[4], e[9];
+    for (int i = 0; i < 8; i++) t[i] = L_IFD((MBLocal *)L)[(by - 1 + 1) * 32 + bx + i + 4];
+    for (int i = 0; i < 4; i++) l[i] = L_IFD((MBLocal *)L)[(by + i + 1) * 32 + bx - 1 + 4];
+    for (int i = 0; i < 4; i++) { e[3 - i] = l[i]; e[5 + i] = t[i]; }
+    e[4] = L_IFD((MBLocal *)L)[(by - 1 + 1) * 32 + bx - 1 + 4];
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        int v;
+        switch (mode) {
+        case 0: v = t[x]; break;
+        case 1: v = l[y]; break;
+        case 2: v = (l[0] + l[1] + l[2] + l[3] + t[0] + t[1] + t[2] + t[3] + 4) >> 3; break;
+        case 9: v = (l[0] + l[1] + l[2] + l[3] + 2) >> 2; break;
+        case 10: v = (t[0] + t[1] + t[2] + t[3] + 2) >> 2; break;
+        case 11: v = 128; break;
+        case 3: v = (x == 3 && y == 3) ? EF2(t[6], t[7], t[7]) : EF2(t[x + y], t[x + y + 1], t[x + y + 2]); break;
+        case 4: { int c = 4 + x - y; v = EF2(e[c - 1], e[c], e[c + 1]); } break;
+        case 5: { int z = 2 * x - y, c = 4 + x - (y >> 1); v = z < -1 ? EF2(e[4 - y], e[5 - y], e[6 - y]) : (z & 1) ? EF2(e[c - 1], e[c], e[c + 1]) : EF1(e[c], e[c + 1]); } break;
+        case 6: { int z = 2 * y - x, r = y - (x >> 1); v = z < -1 ? EF2(e[2 + x], e[3 + x], e[4 + x]) : (z & 1) ? EF2(e[5 - r], e[4 - r], e[3 - r]) : EF1(e[4 - r], e[3 - r]); } break;
+        case 7: { int k = x + (y >> 1); v = (y & 1) ? EF2(t[k], t[k + 1], t[k + 2]) : EF1(t[k], t[k + 1]); } break;
+        default: { int z = x + 2 * y, r = y + (x >> 1); v = z > 5 ? l[3] : z == 5 ? EF2(l[2], l[3], l[3]) : (z & 1) ? EF2(l[r], l[r + 1], l[r + 2]) : EF1(l[r], l[r + 1]); } break;
+        }
+        p[y * 4 + x] = (uint8_t)v;
+    }
+}
+static inline void prim_intra4_costs(const FrameDev &F, MBLocal *L, int idx, int n, int emulate)
+{
+    const int bx = 4 * blk_x_of(idx), by = 4 * blk_y_of(idx);
+    if (emulate) for (int i = 4; i < 8; i++) IFD(L, bx + i, by - 1) = IFD(L, bx + 3, by - 1);
+    for (int i = 0; i < n; i++) {
+        uint8_t p[16];
+        emu_pred4(L, bx, by, L->slots[i], p);
+        L->ccost[i] = emu_cmp(4, 4, p, 4, L->fenc + by * 16 + bx, 16, F.subme > 1);
+    }
+}
+static inline void prim_intra4_encode(const FrameDev &F, MBLocal *L, int idx, int mode)
+{
+    const int bx = 4 * blk_x_of(idx), by = 4 * blk_y_of(idx);
+    uint8_t p[16]; int16_t d[4][4], t[4][4], c[16];
+    emu_pred4(L, bx, by, mode, p);
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y][x] = L->fenc[(by + y) * 16 + bx + x] - p[y * 4 + x];
+    for (int i = 0; i < 4; i++) {
+        int s03 = d[i][0] + d[i][3], s12 = d[i][1] + d[i][2], d03 = d[i][0] - d[i][3], d12 = d[i][1] - d[i][2];
+        t[0][i] = s03 + s12; t[1][i] = 2 * d03 + d12; t[2][i] = s03 - s12; t[3][i] = d03 - 2 * d12;
+    }
+    for (int i = 0; i < 4; i++) {
+        int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+        c[i * 4] = s03 + s12; c[i * 4 + 1] = 2 * d03 + d12; c[i * 4 + 2] = s03 - s12; c[i * 4 + 3] = d03 - 2 * d12;
+    }
+    int nz = 0;
+    for (int i = 0; i < 16; i++) {
+        int cls = (i & 1) + ((i >> 2) & 1), v = c[i];
+        v = v > 0 ? ((F.q_bias_i[cls] + v) * F.q_mf_i[cls] >> 16) : -((F.q_bias_i[cls] - v) * F.q_mf_i[cls] >> 16);
+        c[i] = (int16_t)v; nz |= v;
+    }
+    uint8_t tmp[4 * 16];
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) tmp[y * 16 + x] = p[y * 4 + x];
+    if (nz) {
+        int qbits = F.qp / 6 - 4;
+        for (int i = 0; i < 16; i++) {
+            int cls = (i & 1) + ((i >> 2) & 1);
+            c[i] = qbits >= 0 ? (int16_t)((c[i] * F.dq_mf[cls]) << qbits) : (int16_t)((c[i] * F.dq_mf[cls] + (1 << (-qbits - 1))) >> (-qbits));
+        }
+        emu_idct_add(tmp, c);
+    }
+    for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) IFD(L, bx + x, by + y) = tmp[y * 16 + x];
+}
+/* sums of |Hadamard coefficients| of the 16x16 block at p (stride st): over its sixteen 4x4 transforms, over its four 8x8
+ * transforms, and the pixel sum (common/pixel.c:256-358) */
+static inline void emu_had_sums(const uint8_t *p, int st, int s4[16], int dc4[16], int s8[4])
+{
+    for (int b = 0; b < 16; b++) {
+        const uint8_t zero[4] = {0};
+        const int x = 4 * (b & 3), y = 4 * (b >> 2);
+        s4[b] = emu_had4(p + y * st + x, st, zero, 0);
+        dc4[b] = 0;
+        for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) dc4[b] += p[(y + j) * st + x + i];
+    }
+    for (int b = 0; b < 4; b++) {
+        int d[8][8];
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) d[y][x] = p[(8 * (b >> 1) + y) * st + 8 * (b & 1) + x];
+        for (int pass = 0; pass < 2; pass++)
+            for (int i = 0; i < 8; i++) {
+                int v[8];
+                for (int k = 0; k < 8; k++) v[k] = pass ? d[k][i] : d[i][k];
+                for (int step = 1; step < 8; step <<= 1) for (int k = 0; k < 8; k++) if (!(k & step)) { int a = v[k], c = v[k + step]; v[k] = a + c; v[k + step] = a - c; }
+                for (int k = 0; k < 8; k++) { if (pass) d[k][i] = v[k]; else d[i][k] = v[k]; }
+            }
+        s8[b] = 0;
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) s8[b] += iabs(d[y][x]);
+    }
+}
+static inline void prim_fenc_complexity(const FrameDev &F, MBLocal *L)     /* x264_mb_cache_fenc_satd, analyse.c:522-549 */
+{
+    L->fenc_satd_sum = L->fenc_sa8d_sum = 0;
+    if (!F.psy_rd) return;
+    int s4[16], dc4[16], s8[4];
+    emu_had_sums(L->fenc, 16, s4, dc4, s8);
+    for (int b = 0; b < 16; b++) L->fenc_satd_sum += (s4[b] >> 1) - (dc4[b] >> 1);
+    for (int b = 0; b < 4; b++) {
+        const int r = 4 * (b >> 1) * 2 + 2 * (b & 1);      /* first 4x4 (raster) of 8x8 b */
+        const int dc = dc4[r] + dc4[r + 1] + dc4[r + 4] + dc4[r + 5];
+        L->fenc_sa8d_sum += ((s8[b] + 2) >> 2) - (dc >> 2);
+    }
+}
+static inline int prim_ssd_mb(const FrameDev &F, MBLocal *L)                /* ssd_mb, rdo.c:106-137 */
+{
+    int ssd = 0;
+    for (int y = 0; y < 24; y++) for (int x = 0; x < 16; x++) { int d = L->fenc[y * 16 + x] - L->pred[y * 16 + x]; ssd += d * d; }
+    if (F.psy_rd) {
+        int s4[16], dc4[16], s8[4], sum4 = 0, sum8 = 0, dc = 0;
+        emu_had_sums(L->pred, 16, s4, dc4, s8);
+        for (int b = 0; b < 16; b++) { sum4 += s4[b]; dc += dc4[b]; }
+        for (int b = 0; b < 4; b++) sum8 += s8[b];
+        int satd = (iabs(((sum4 - dc) >> 1) - L->fenc_satd_sum) + iabs(((sum8 - dc) >> 2) - L->fenc_sa8d_sum)) >> 1;
+        ssd += (satd * F.psy_rd * F.lambda + 128) >> 8;
+    }
+    return ssd;
+}
+static inline void prim_cabac_trial_begin(MBLocal *L) { memcpy(L_CAB(L, 1), L_CAB(L, 0), 88); }
+/* residual_block_cabac for every coded block of the macroblock (encoder/cabac.c:582-667, 1000-1018): the header contexts of a
+ * trial are the copy, the residual contexts are read from the slice states and only written back when committing */
+static inline int prim_cabac_residual(const FrameDev &F, MBLocal *L, int commit)
+{
+    static const uint16_t sig_off[5] = {105, 120, 134, 149, 152}, last_off[5] = {166, 181, 195, 210, 213}, lvl_off[5] = {227, 237, 247, 257, 266};
+    static const uint8_t lvl1[8] = {1, 2, 3, 4, 0, 0, 0, 0}, lvlgt1[8] = {5, 5, 5, 5, 6, 7, 8, 9}, nxt[2][8] = {{1, 2, 3, 3, 4, 5, 6, 7}, {4, 4, 4, 4, 5, 6, 7, 7}};
+    uint8_t tmp[464];
+    uint8_t *S = L_CAB(L, 0);
+    if (!commit) { memcpy(tmp, S, 464); S = tmp; }
+    int bits = 0;
+    (void)F;
+    if (!(L->cbp_luma | L->cbp_chroma)) return 0;
+    for (int pass = 0; pass < 3; pass++) {
+        const int cat = 2 + pass, first = pass == 0 ? 0 : pass == 1 ? 25 : 16, nb = pass == 0 ? 16 : pass == 1 ? 2 : 8, count = pass == 0 ? 16 : pass == 1 ? 4 : 15;
+        if (pass == 1 && !(L->cbp_chroma & 3)) continue;
+        if (pass == 2 && !(L->cbp_chroma & 2)) continue;
+        for (int k = 0; k < nb; k++) {
+            const int idx = first + k;
+            if (pass == 0 && !(L->cbp_luma & (1 << (k >> 2)))) continue;
+            int inc;
+            if (cat == 3) {
+                const int a = L->cbp_left != -1 ? (L->cbp_left >> (9 + k)) & 1 : 0, b = L->cbp_top != -1 ? (L->cbp_top >> (9 + k)) & 1 : 0;
+                inc = 4 * cat + 2 * b + a;
+            } else {
+                const int a = L->nzc[scan8_all_of(idx) - 1] & 0x7f, b = L->nzc[scan8_all_of(idx) - 8] & 0x7f;
+                inc = 4 * cat + 2 * !!b + !!a;
+            }
+            const int16_t *l = pass == 1 ? L->cdc[k] : pass == 2 ? L->coef[idx] + 1 : L->coef[idx];
+            const int flag = L->nzc[scan8_all_of(idx)] != 0;
+            cb_dec(L, S, 85 + inc, flag, &bits);
+            if (!flag) continue;
+            int last = count - 1;
+            while (last >= 0 && !l[last]) last--;
+            for (int i = 0; i < imin(last + 1, count - 1); i++) {
+                cb_dec(L, S, sig_off[cat] + i, l[i] != 0, &bits);
+                if (l[i]) cb_dec(L, S, last_off[cat] + i, i == last, &bits);
+            }
+            int node = 0;
+            for (int i = last; i >= 0; i--) {
+                if (!l[i]) continue;
+                const int am1 = iabs(l[i]) - 1, prefix = imin(am1, 14);
+                if (prefix) {
+                    cb_dec(L, S, lvl_off[cat] + lvl1[node], 1, &bits);
+                    for (int q = 0; q < prefix - 1; q++) cb_dec(L, S, lvl_off[cat] + lvlgt1[node], 1, &bits);
+                    if (prefix < 14) cb_dec(L, S, lvl_off[cat] + lvlgt1[node], 0, &bits); else bits += size_ue_of((unsigned)(am1 - 14)) << 8;
+                    node = nxt[1][node];
+                } else { cb_dec(L, S, lvl_off[cat] + lvl1[node], 0, &bits); node = nxt[0][node]; }
+                bits += 256;
+            }
+        }
+    }
+    return bits;
+}
+static inline int emu_cavlc_level(int level, int *suffix_len)
+{
+    int sl = *suffix_len, a = iabs(level), code = a * 2 - 2 + (level < 0), size, next = sl;
+    if ((code >> sl) < 14) size = (code >> sl) + 1 + sl;
+    else if (sl == 0 && code < 30) size = 19;
+    else if (sl > 0 && (code >> sl) == 14) size = 15 + sl;
+    else { code -= 15 << sl; if (sl == 0) code -= 15; size = 28; if (code >= 1 << 12) size += 1000000; }
+    if (next == 0) next++;
+    if (a > (3 << (next - 1)) && next < 6) next++;
+    *suffix_len = next;
+    return size;
+}
+static inline int emu_cavlc_block(MBLocal *L, int idx, const int16_t *l, int count)
+{
+    static const uint8_t ct_index[17] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3};
+    int nC = 4, bits = 0;
+    if (idx < 25) { int r = L->nzc[scan8_all_of(idx) - 1] + L->nzc[scan8_all_of(idx) - 8]; if (r < 0x80) r = (r + 1) >> 1; nC = ct_index[r & 0x7f]; }
+    if (!L->nzc[scan8_all_of(idx)]) return pcamv_vlc_coeff0_len[nC];
+    int level[16], run[16], last = count - 1, total = 0;
+    while (last >= 0 && !l[last]) last--;
+    for (int i = last; i >= 0;) { int r = 0; level[total] = l[i]; while (--i >= 0 && !l[i]) r++; run[total++] = r; }
+    int total_zero = last + 1 - total, trailing = 0;
+    L->nzc[scan8_all_of(idx)] = (uint8_t)total;
+    while (trailing < 3 && trailing < total && iabs(level[trailing]) == 1) trailing++;
+    bits += pcamv_vlc_coeff_len[nC * 64 + total * 4 + trailing - 4] + trailing;
+    int sl = total > 10 && trailing < 3;
+    if (trailing < total) {
+        int v = level[trailing], s1 = sl, s2 = sl;
+        if (trailing < 3) v -= v < 0 ? -1 : 1;
+        bits += emu_cavlc_level(v, &s1);
+        emu_cavlc_level(level[trailing], &s2); sl = s2;
+        for (int i = trailing + 1; i < total; i++) bits += emu_cavlc_level(level[i], &sl);
+    }
+    if (total < count) bits += idx >= 25 ? pcamv_vlc_total_zeros_dc_len[(total - 1) * 4 + total_zero] : pcamv_vlc_total_zeros_len[(total - 1) * 16 + total_zero];
+    for (int i = 0; i < total - 1 && total_zero > 0; i++) { bits += pcamv_vlc_run_before_len[imin(total_zero - 1, 6) * 16 + run[i]]; total_zero -= run[i]; }
+    return bits;
+}
+static inline int emu_size_se(int v) { return size_ue_of((unsigned)(v <= 0 ? -v * 2 : v * 2 - 1)); }
+/* x264_macroblock_write_cavlc as a bit counter (encoder/cavlc.c:290-600, rdo.c:41-47): leaves the coefficient counts in L->nzc */
+static inline int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
+{
+    static const uint8_t cbp_golomb[48] = {0, 2, 3, 7, 4, 8, 17, 13, 5, 18, 9, 14, 10, 15, 16, 11, 1, 32, 33, 36, 34, 37, 44, 40,
+                                           35, 45, 38, 41, 39, 42, 43, 19, 6, 24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+    static const uint8_t sub_golomb[4] = {3, 1, 2, 0};
+    int bits = 0, mvp[2];
+    (void)F;
+#define EMVD(idx, w) (predict_mv(L, idx, w, mvp), emu_size_se(L->cmv[scan8_of(idx)][0] - mvp[0]) + emu_size_se(L->cmv[scan8_of(idx)][1] - mvp[1]))
+    if (L->i_type == PCAMV_P_8x8) {
+        bits += size_ue_of(3);
+        for (int i = 0; i < 4; i++) bits += size_ue_of(sub_golomb[L->sub_part[i]]);
+        for (int i = 0; i < 4; i++)
+            switch (L->sub_part[i]) {
+            case PCAMV_D_L0_8x8: bits += EMVD(4 * i, 2); break;
+            case PCAMV_D_L0_8x4: bits += EMVD(4 * i, 2); bits += EMVD(4 * i + 2, 2); break;
+            case PCAMV_D_L0_4x8: bits += EMVD(4 * i, 1); bits += EMVD(4 * i + 1, 1); break;
+            default: for (int k = 0; k < 4; k++) bits += EMVD(4 * i + k, 1); break;
+            }
+    } else if (L->i_partition == PCAMV_D_16x16) { bits += size_ue_of(0); bits += EMVD(0, 4); }
+    else if (L->i_partition == PCAMV_D_16x8) { bits += size_ue_of(1); bits += EMVD(0, 4); bits += EMVD(8, 4); }
+    else { bits += size_ue_of(2); bits += EMVD(0, 2); bits += EMVD(4, 2); }
+#undef EMVD
+    bits += size_ue_of(cbp_golomb[(L->cbp_chroma << 4) | L->cbp_luma]);
+    if (L->cbp_luma | L->cbp_chroma) {
+        bits += 1;
+        for (int i = 0; i < 16; i++) if (L->cbp_luma & (1 << (i / 4))) bits += emu_cavlc_block(L, i, L->coef[i], 16);
+    }
+    if (L->cbp_chroma) {
+        bits += emu_cavlc_block(L, 25, L->cdc[0], 4) + emu_cavlc_block(L, 26, L->cdc[1], 4);
+        if (L->cbp_chroma & 2) for (int i = 16; i < 24; i++) bits += emu_cavlc_block(L, i, L->coef[i] + 1, 15);
+    }
+    return bits;
+}
+static inline void prim_rd_commit(const FrameDev &F, MBLocal *L, int skip)
+{
+    static const uint8_t bottom[8] = {10, 11, 14, 15, 18, 19, 22, 23}, right[8] = {5, 7, 13, 15, 17, 19, 21, 23};
+    const int xy = L->mb_xy;
+    for (int k = 0; k < 8; k++) {
+        F.nb_nz[xy * 16 + k] = skip ? 0 : L->nzc[scan8_all_of(bottom[k])];
+        F.nb_nz[xy * 16 + 8 + k] = skip ? 0 : L->nzc[scan8_all_of(right[k])];
+    }
+    F.nb_cbp[xy] = skip ? 0 : (int16_t)((F.b_cabac ? (L->nzc[scan8_all_of(25)] << 9 | L->nzc[scan8_all_of(26)] << 10) : 0) | L->cbp_chroma << 4 | L->cbp_luma);
+    for (int k = 0; k < 4; k++) {
+        const int16_t *b = L->cmvd[SCAN8_0 + k + 8 * 3], *r = L->cmvd[SCAN8_0 + 3 + 8 * k];
+        F.nb_mvd[(xy * 8 + k) * 2] = skip ? 0 : b[0]; F.nb_mvd[(xy * 8 + k) * 2 + 1] = skip ? 0 : b[1];
+        F.nb_mvd[(xy * 8 + 4 + k) * 2] = skip ? 0 : r[0]; F.nb_mvd[(xy * 8 + 4 + k) * 2 + 1] = skip ? 0 : r[1];
+    }
+    if (F.b_cabac) {
+        memcpy(F.cabac, L_CAB(L, 0), 464);
+        if (F.dbg_hash) { uint32_t h = 2166136261u; for (int i = 0; i < 460; i++) h = (h ^ L_CAB(L, 0)[i]) * 16777619u; F.dbg_hash[xy] = h; }
+    }
 }
 static inline int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)
 {

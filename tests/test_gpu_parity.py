@@ -23,21 +23,36 @@ def pc():
     return pcamv_amd
 
 
-def _params(pc, W, H, me, subme, inter, mv_range, me_range=16, tscale=256):
+def _params(pc, W, H, me, subme, inter, mv_range, me_range=16, tscale=256, cabac=1, psy_fix8=None, chroma_qp_offset=None):
     p = pc.param_default(W, H)
-    p.i_me_method, p.i_subpel_refine, p.inter, p.i_mv_range, p.i_me_range, p.i_tscale = me, subme, inter, mv_range, me_range, tscale
+    pc.param_parse(p, "subme", subme)       # also settles psy-RD / the chroma QP offset the way x264_validate_parameters does
+    p.i_me_method, p.inter, p.i_mv_range, p.i_me_range, p.i_tscale, p.b_cabac = me, inter | 1, mv_range, me_range, tscale, cabac
+    if psy_fix8 is not None:
+        p.i_psy_rd, p.i_chroma_qp_offset = psy_fix8, chroma_qp_offset
     return p
+
+
+def _fixture_params(pc, g):
+    kw = {}
+    if "cabac" in g:
+        kw = dict(cabac=int(g["cabac"]), psy_fix8=int(g["psy_rd_fix8"]), chroma_qp_offset=int(g["chroma_qp_offset"]))
+    return _params(pc, int(g["width"]), int(g["height"]), int(g["me"]), int(g["subme"]), int(g["inter"]), int(g["mv_range"]), int(g["me_range"]), **kw)
 
 
 GPU_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub8", "qcif_esa_subme3", "qcif_tesa_subme5_psub8", "qcif_hex_noisy_partitions", "cif_umh_subme5"]
 
 
-@pytest.mark.parametrize("name", GPU_FIXTURES)
+@pytest.mark.parametrize("name", GPU_FIXTURES + helpers.RD_FIXTURES)
 def test_pframe_analysis_matches_reference_fixture(pc, name):
+    """every field of the pass-1 record, the reconstruction and the half-pel planes against what the reference's own code
+    computed; for --subme 6 / 7 with CABAC also the context states after every macroblock"""
     g = helpers.load(name)
     W, H = int(g["width"]), int(g["height"])
-    p = _params(pc, W, H, int(g["me"]), int(g["subme"]), int(g["inter"]), int(g["mv_range"]), int(g["me_range"]))
-    enc = pc.Encoder(p)
+    embed = int(g["embed"]) if "embed" in g else 1
+    enc = pc.Encoder(_fixture_params(pc, g))
+    want_hash = "f1_cabac_state_hash" in g
+    if want_hash:
+        enc.debug_state_hash(True)
     for t in range(1, int(g["frames"]) + 1):
         prev = (g[f"f{t}_prev_mv"], g[f"f{t}_prev_ref"]) if f"f{t}_prev_mv" in g else (None, None)
         enc.set_ref(g[f"f{t}_ref_y"], g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev)
@@ -45,7 +60,10 @@ def test_pframe_analysis_matches_reference_fixture(pc, name):
         planes = enc.ref_planes()
         for k in range(4):
             assert sha(planes[k]) == str(g[f"f{t}_plane_sha"][k]), f"{name} frame {t}: half-pel plane {k}"
-        mbs, rec = enc.analyse_pframe(int(g["qp"]), embed=1)
+        mbs, rec = enc.analyse_pframe(int(g["qp"]), embed=embed)
+        if want_hash:
+            bad = np.nonzero(enc.state_hash_fetch() != g[f"f{t}_cabac_state_hash"])[0]
+            assert len(bad) == 0, f"{name} frame {t}: CABAC context states differ from macroblock {bad[0]} on ({len(bad)} in all)"
         helpers.compare_records(g[f"f{t}_mbs"], mbs, f"{name} frame {t}")
         for k, nm in enumerate("yuv"):
             assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
@@ -104,6 +122,54 @@ def test_block_costs_match_oracle(pc):
             sreq.append([r[0], r[1], r[2], r[3], r[4], r[5] + dx, r[6] + dy, r[7] & 1])
     sgot = enc.block_costs(26, sreq)[:, 0].reshape(-1, 3)
     assert np.array_equal(bgot, sgot), np.argwhere(bgot != sgot)[:5]
+    enc.close(); o.close()
+
+
+RD_SWEEP = [
+    # (W, H, me, subme, qp, seed, static_cols, cabac, psy_rd, noise, embed)
+    (176, 144, "hex", 6, 12, 51, 32, 1, 1.0, 40, 1),       # low QP: long level prefixes / escapes
+    (176, 144, "hex", 7, 20, 52, 32, 0, 1.0, 40, 1),       # CAVLC, noisy: many coded blocks, partitions
+    (176, 144, "umh", 6, 38, 53, 0, 1, 2.0, 25, 1),        # strong psy-RD, coarse quantiser
+    (176, 144, "dia", 7, 45, 54, 48, 0, 0.1, 6, 1),        # psy-RD below 0.25 (chroma QP offset -1), CAVLC
+    (176, 144, "esa", 6, 30, 55, 16, 1, 0.0, 40, 0),       # embedding off: no P_8x8 from the RD stage (analyse.c:2841)
+    (352, 288, "hex", 6, 28, 56, 64, 0, 1.0, 12, 1),
+    (320, 240, "umh", 7, 26, 57, 96, 1, 1.0, 6, 1),        # config 3's options (--me umh --subme 7) on a wider picture
+    (1280, 720, "hex", 6, 26, 11, 320, 1, 1.0, 6, 1),      # 720p: the raster chain over 3600 macroblocks
+]
+
+
+@pytest.mark.parametrize("cfg", RD_SWEEP, ids=[f"{c[0]}x{c[1]}_{c[2]}_s{c[3]}_qp{c[4]}_{'cabac' if c[7] else 'cavlc'}_psy{c[8]}_e{c[10]}" for c in RD_SWEEP])
+def test_rd_mode_decision_matches_oracle(pc, cfg):
+    """--subme 6 / 7 (the reference's default): intra SATD thresholds, psy-RD, size-only CABAC / CAVLC, context adaptation --
+    record, reconstruction and (CABAC) the context states after every macroblock against the oracle (pinned on the reference's
+    code by tests/golden/*subme6* / *subme7* and tests/test_oracle_vs_ref_live.py); two chained P frames"""
+    import orc
+    from pcamv_amd.synth import make_clip
+    W, H, me, subme, qp, seed, static, cabac, psy, noise, embed = cfg
+    clip = make_clip(W, H, 3, seed=seed, static_cols=static, noise=noise)
+    mvr = pc.level_mv_range(W, H)
+    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=0x11, cabac=cabac, psy_rd=psy)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr, cabac=cabac, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset)
+    enc = pc.Encoder(p)
+    o = orc.Oracle(op)
+    ho = o.debug_state_hash()
+    if cabac:
+        enc.debug_state_hash(True)
+    ref, prev = clip[0], (None, None)
+    for t in (1, 2):
+        enc.set_ref(*ref, *prev); enc.upload_fenc(*clip[t])
+        o.set_ref(*ref, *prev); o.set_fenc(*clip[t])
+        mbs, rec = enc.analyse_pframe(qp, embed=embed)
+        mbs_o, rec_o = o.analyse_pframe(qp, embed)
+        if cabac:
+            bad = np.nonzero(enc.state_hash_fetch() != ho)[0]
+            assert len(bad) == 0, f"frame {t}: CABAC context states differ from macroblock {bad[0]} on ({len(bad)} in all)"
+        for f in mbs.dtype.names:
+            assert np.array_equal(mbs[f], mbs_o[f]), f"frame {t}: {f} at MBs {np.argwhere((mbs[f] != mbs_o[f]).reshape(len(mbs), -1).any(1)).ravel()[:6]}"
+        for a, b in zip(rec, rec_o):
+            assert np.array_equal(a, b), f"frame {t}: reconstruction"
+        prev = helpers.mv_field(mbs["mv"], W // 16, H // 16)
+        ref = rec
     enc.close(); o.close()
 
 
@@ -185,14 +251,24 @@ def test_embedding_edge_cases(pc):
 
 def test_open_rejects_unsupported(pc):
     p = pc.param_default(176, 144)
-    p.i_subpel_refine = 7
+    pc.param_parse(p, "subme", 8)            # RD refinement of the MVs: not built (and disabled in the fork's P frames, analyse.c:3112)
+    with pytest.raises(pc.PcamvError):
+        pc.Encoder(p)
+    p = pc.param_default(176, 144)
+    pc.param_parse(p, "partitions", "i4x4,p8x8,p4x4")     # subme 6 (the default) with sub-8x8 partitions: x264_rd_cost_part is not built
+    with pytest.raises(pc.PcamvError):
+        pc.Encoder(p)
+    pc.param_parse(p, "subme", 5)            # ... fine without the RD stage
+    pc.Encoder(p).close()
+    p = pc.param_default(176, 144)
+    pc.param_parse(p, "me", "tesa")          # the default subme 6 with --me tesa: not built
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)
     p = pc.param_default(170, 144)
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)
     p = pc.param_default(176, 144)      # --me tesa keeps its survivor list in LDS: up to me_range 16
-    pc.param_parse(p, "me", "tesa")
+    pc.param_parse(p, "me", "tesa"); pc.param_parse(p, "subme", 5)
     p.i_me_range = 24
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)

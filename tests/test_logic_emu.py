@@ -30,3 +30,31 @@ def test_control_logic_matches_reference(name, order):
         for k, nm in enumerate("yuv"):
             assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
     o.close()
+
+
+# --subme 6 / 7: the RD mode decision in the shared control code.  With CABAC the context states chain the macroblocks of a
+# frame in raster order (order 3: raster, fused); CAVLC sizes depend on the left / top neighbours only, so the dataflow
+# schedule's orders apply as well.
+RD = [(n, o) for n in helpers.RD_FIXTURES for o in ((3,) if "cavlc" not in n else (1, 2, 3))]
+
+
+@pytest.mark.parametrize("name,order", RD, ids=[f"{n}-order{o}" for n, o in RD])
+def test_rd_mode_decision_logic_matches_reference(name, order):
+    g = helpers.load(name)
+    W, H = int(g["width"]), int(g["height"])
+    p = helpers.fixture_params(g, orc.make_params)
+    embed = int(g["embed"])
+    o = orc.Oracle(p)     # used only to produce the padded half-pel planes the kernels read
+    for t in range(1, int(g["frames"]) + 1):
+        prev = (g[f"f{t}_prev_mv"], g[f"f{t}_prev_ref"]) if f"f{t}_prev_mv" in g else (None, None)
+        o.set_ref(g[f"f{t}_ref_y"], g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev)
+        hashes = np.zeros(len(g[f"f{t}_mbs"]), np.uint32)
+        mbs, rec = emu.analyse_pframe(orc, p, int(g["qp"]), embed, [g[f"f{t}_fenc_{c}"] for c in "yuv"], o.ref_planes(),
+                                      g[f"f{t}_ref_u"], g[f"f{t}_ref_v"], *prev, diag=order, state_hash=hashes)
+        if f"f{t}_cabac_state_hash" in g:
+            bad = np.nonzero(hashes != g[f"f{t}_cabac_state_hash"])[0]
+            assert len(bad) == 0, f"{name} frame {t}: CABAC context states differ from macroblock {bad[0]} on"
+        helpers.compare_records(g[f"f{t}_mbs"], mbs, f"{name} frame {t}")
+        for k, nm in enumerate("yuv"):
+            assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
+    o.close()

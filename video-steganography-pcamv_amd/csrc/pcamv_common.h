@@ -71,6 +71,17 @@ struct FrameDev {
     uint16_t *nnz;                 /* [n_mb] bit i: luma 4x4 block i (x264 block order) kept non-zero levels */
     const int8_t *flip;            /* flip map of the embedding stage, one entry per carrier MV in embedding order */
     const int *car_base;           /* [n_mb] index of the macroblock's first carrier in that order */
+    /* --subme >= 6: RD mode decision (encoder/rdo.c).  What the entropy coder's contexts of the right / lower neighbours
+     * read from a coded macroblock, and the slice's CABAC context states handed from macroblock to macroblock */
+    int b_mbrd, psy_rd, lambda2, ref_is_inter;
+    int q_mf_i[3], q_bias_i[3];    /* intra luma quantiser (CQM_4IY) at qp, for the 4x4 intra analysis */
+    uint8_t *nb_nz;                /* [n_mb][16] non-zero flags (CABAC) / coefficient counts (CAVLC): 0..7 bottom row (4 luma, 2 Cb, 2 Cr), 8..15 right column */
+    int16_t *nb_cbp;               /* [n_mb] h->mb.cbp: luma | chroma << 4 | chroma DC coded bits << 9 */
+    int16_t *nb_mvd;               /* [n_mb][8][2] MV differences of the bottom row (0..3) and right column (4..7) of 4x4 blocks */
+    uint8_t *cabac;                /* [464] context states after the macroblock coded last (460 used) */
+    const uint8_t *cabac_init;     /* [464] states at the slice start for this QP (H.264 9.3.1.1, cabac_init_idc 0) */
+    const uint32_t *cabac_tab;     /* [256] per (state, bin): 8.8 fixed-point bits << 8 | next state */
+    uint32_t *dbg_hash;            /* diagnostics: [n_mb] FNV-1a of the context states after each macroblock, or NULL */
 };
 
 /* Small lookup tables live in registers as packed constants: a table in memory costs one global
@@ -91,6 +102,9 @@ PCAMV_DEV int iabs(int v) { return v < 0 ? -v : v; }
 PCAMV_DEV int imin(int a, int b) { return a < b ? a : b; }
 PCAMV_DEV int imax(int a, int b) { return a > b ? a : b; }
 PCAMV_DEV int median3i(int a, int b, int c) { return imax(imin(a, b), imin(imax(a, b), c)); }
+PCAMV_DEV int size_ue_of(unsigned v) { int n = 0; for (v++; v > 1; v >>= 1) n++; return 2 * n + 1; }   /* Exp-Golomb code length (common/bs.h:174-273) */
+/* intra 4x4 prediction modes (common/predict.h:76-92) */
+enum { I4_V, I4_H, I4_DC, I4_DDL, I4_DDR, I4_VR, I4_HD, I4_VL, I4_HU, I4_DC_LEFT, I4_DC_TOP, I4_DC_128 };
 
 /* Per-macroblock working set.  On the GPU this lives in LDS (one wavefront = one macroblock);
  * every lane executes the control code redundantly on wave-uniform values. */
@@ -129,7 +143,30 @@ struct MBLocal {
      * the reference pixels of its re-encodes and nine-point lists */
     uint32_t win[(4 * 480 + 2 * 192) / 4];
     int win_x0, win_y0, win_cx0, win_cy0;     /* plane coordinates (padded-plane origin) of the window's first byte */
+    /* --subme >= 6 */
+    uint8_t ib_top[3][28];         /* intra prediction neighbours (unfiltered pass-1 reconstruction): the line above, [c][3] = top left, [c][4 + x] */
+    uint8_t ib_left[3][16];        /* ... and the column to the left */
+    uint8_t nzc[48];               /* h->mb.cache.non_zero_count (scan8 layout; 0x80 = unavailable) */
+    int16_t cmvd[48][2];           /* h->mb.cache.mvd */
+    int8_t i4mode[48];             /* h->mb.cache.intra4x4_pred_mode */
+    int cbp_left, cbp_top;         /* h->mb.cache.i_cbp_left / top, -1 = unavailable */
+    int b_fast_intra, fenc_satd_sum, fenc_sa8d_sum;
 };
+/* Storage that is idle while the RD decision runs is reused (no LDS growth): the RCA reference window holds the CABAC
+ * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA
+ * reconstruction buffers hold the intra 4x4 analysis' picture (17 rows of 32: row -1 and column -1 are the neighbours);
+ * the P_SKIP probe's coefficient scratch (coef / cdc) holds a trial's quantised levels in scan order. */
+#define L_CAB(L, k) ((uint8_t *)(L)->win + 464 * (k))
+#define L_CTAB(L) ((L)->win + 232)
+#define L_IFD(L) ((uint8_t *)(L)->recb)
+#define IFD(L, x, y) (L_IFD(L)[((y) + 1) * 32 + (x) + 4])
+/* common/common.h:217-238: cache position of block idx (0..15 luma, 16..19 Cb, 20..23 Cr, 24 luma DC, 25 Cb DC, 26 Cr DC) */
+PCAMV_DEV int scan8_all_of(int idx)
+{
+    if (idx < 16) return scan8_of(idx);
+    if (idx < 24) return 1 + ((idx - 16) & 1) + 8 * (1 + (((idx - 16) >> 1) & 1) + 3 * ((idx - 16) >> 2));
+    return 4 + (idx - 24) + 5 * 8;
+}
 
 /* TESA (me.c:525-600): the positions that survive the ADS / SAD thresholds, one word each: (SAD + MV bits) << 12 |
  * window row << 6 | window column.  Up to 32 x 33 of them (me_range <= 16); they live in LDS that is idle while a
@@ -217,7 +254,7 @@ struct MEState {
 
 /* diagnostics build (-DPCAMV_PROF): wave cycles per phase of k_analyse_flow, summed in pcamv_prof[] (tools/dbg/prof_phases.py) */
 #if defined(PCAMV_PROF) && !defined(PCAMV_HOST_EMU)
-static __device__ unsigned long long pcamv_prof[16];
+static __device__ unsigned long long pcamv_prof[24];
 #define PROF_T() __builtin_readcyclecounter()
 #define PROF_ADD(i, t0) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(PROF_T() - (t0))); } while (0)
 #else

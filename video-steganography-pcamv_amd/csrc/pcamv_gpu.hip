@@ -13,7 +13,7 @@
 #include "pcamv_kernels.hip.h"
 #include "pcamv_host_tables.h"
 
-#define PCAMV_ABI_VERSION 1
+#define PCAMV_ABI_VERSION 2
 #define NEV 32
 #define NRING 8
 
@@ -58,6 +58,8 @@ struct pcamv_ctx {
     int cap;
     int *d_trace;
     uint16_t *d_nnz; int *d_car_base; int8_t *d_flip_user;     /* pass 2 */
+    /* --subme >= 6 */
+    uint8_t *d_nb_nz, *d_cabac, *d_cabac_init[52]; int16_t *d_nb_cbp, *d_nb_mvd; uint32_t *d_cabac_tab, *d_dbg_hash;
     char err[256];
 };
 
@@ -76,10 +78,14 @@ static int bfail(pcamv_batch *b, int code, const char *fmt, ...)
 
 extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 #ifdef PCAMV_PROF
+int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    unsigned long long rd[24];
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (pcamv_rd_prof_fetch(rd, reset)) return -1;
+    for (int i = 0; i < 24; i++) out[i] += rd[i];
     return 0;
 }
 #endif
@@ -131,7 +137,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     *out = NULL;
     for (int i = 0; i < n; i++)
         if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device || ctxs[i]->F.w != ctxs[0]->F.w || ctxs[i]->F.h != ctxs[0]->F.h ||
-            ctxs[i]->p.inter != ctxs[0]->p.inter) return PCAMV_EINVAL;
+            ctxs[i]->p.inter != ctxs[0]->p.inter || ctxs[i]->F.b_mbrd != ctxs[0]->F.b_mbrd || ctxs[i]->F.b_cabac != ctxs[0]->F.b_cabac) return PCAMV_EINVAL;
     pcamv_batch *b = new (std::nothrow) pcamv_batch();
     if (!b) return PCAMV_ENOMEM;
     memset((void *)b, 0, sizeof(*b));
@@ -166,8 +172,10 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         }
         b->fl.total = (unsigned)total; b->fl.spin_limit = 4u << 20;
         b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1; b->fl.unit = 1;
+        b->fl.raster = F.b_mbrd && F.b_cabac;
         int per_cu = 0, n_cu = 0;
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow, 64, 0);
+        if (e == hipSuccess && F.b_mbrd) { per_cu = pcamv_flow_rd_waves_per_cu(); if (per_cu < 0) e = hipErrorUnknown; }
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device);
         const char *wv = getenv("PCAMV_FLOW_WAVES");
         long waves = wv ? atol(wv) : (long)per_cu * n_cu;
@@ -182,7 +190,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
          * same on the coarser grid).  Measured at G=256: 115.1 / 114.7 / 116.9 / 122.6 ms per step for 1 / 2 / 4 / 8 --
          * its queue traffic is not what bounds it any more; default 1.  Same buffers: the two kernels never overlap. */
         { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : 1;
-          b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
+          b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.raster = 0; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
           b->fl2.total = (unsigned)n * (unsigned)b->fl2.n_mb;
           unsigned qb2 = 0;
           for (int q = 0; q < 8; q++) { b->fl2.qbase[q] = qb2; b->fl2.qcount[q] = b->fl.qcount[q] / (unsigned)F.n_mb * (unsigned)b->fl2.n_mb; qb2 += b->fl2.qcount[q]; }
@@ -193,7 +201,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     }
     if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
     for (int i = 0; i < n; i++)         /* the kernel instance with --me tesa compiled in exists for the dataflow schedule only */
-        if (ctxs[i]->F.me_method == PCAMV_ME_TESA && !b->sched_flow) { pcamv_gpu_batch_destroy(b); return PCAMV_EUNSUP; }
+        if ((ctxs[i]->F.me_method == PCAMV_ME_TESA || ctxs[i]->F.b_mbrd) && !b->sched_flow) { pcamv_gpu_batch_destroy(b); return PCAMV_EUNSUP; }     /* ... and so does the RD mode decision */
     *out = b;
     return 0;
 }
@@ -227,7 +235,10 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     if (!p || !out) return PCAMV_EINVAL;
     *out = NULL;
     if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
-    if (p->i_subpel_refine < 1 || p->i_subpel_refine > 5) return PCAMV_EUNSUP;   /* >=6 needs CABAC-size RDO */
+    if (p->i_subpel_refine < 1 || p->i_subpel_refine > 7) return PCAMV_EUNSUP;   /* 8, 9: RD refinement of the MVs (disabled in the fork's P frames anyway, analyse.c:3112) */
+    /* RD mode decision (6, 7): not with sub-8x8 partitions (x264_rd_cost_part not built) nor with --me tesa (its survivor
+     * list and the context states want the same LDS) */
+    if (p->i_subpel_refine >= 6 && ((p->inter & PCAMV_ANALYSE_PSUB8x8) || p->i_me_method == PCAMV_ME_TESA)) return PCAMV_EUNSUP;
     if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_TESA) return PCAMV_EUNSUP;
     if (p->i_me_method == PCAMV_ME_TESA && p->i_me_range > TESA_MAX_RANGE) return PCAMV_EUNSUP;      /* the survivor list lives in LDS: 32 x 33 positions */
     if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
@@ -268,6 +279,15 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     HIPCHK(c, dalloc(&c->d_nnz, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_car_base, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_flip_user, (size_t)c->cap));
     HIPCHK(c, hipMemset(c->d_nnz, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_car_base, 0, (size_t)F.n_mb * 4));
     HIPCHK(c, hipMemset(c->d_hdr, 0, 8 * sizeof(int)));
+    if (F.b_mbrd) {
+        HIPCHK(c, dalloc(&c->d_nb_nz, (size_t)F.n_mb * 16)); HIPCHK(c, dalloc(&c->d_nb_cbp, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_nb_mvd, (size_t)F.n_mb * 16));
+        HIPCHK(c, dalloc(&c->d_cabac, 464)); HIPCHK(c, dalloc(&c->d_cabac_tab, 256));
+        HIPCHK(c, hipMemset(c->d_nb_nz, 0, (size_t)F.n_mb * 16)); HIPCHK(c, hipMemset(c->d_nb_cbp, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_nb_mvd, 0, (size_t)F.n_mb * 32));
+        HIPCHK(c, hipMemset(c->d_cabac, 0, 464));
+        uint32_t tab[256]; pcamv_build_cabac_tab(tab);
+        HIPCHK(c, hipMemcpy(c->d_cabac_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        F.nb_nz = c->d_nb_nz; F.nb_cbp = c->d_nb_cbp; F.nb_mvd = c->d_nb_mvd; F.cabac = c->d_cabac; F.cabac_tab = c->d_cabac_tab;
+    }
     int rnd[40]; memset(rnd, 0, sizeof(rnd)); glibc_srand_state(rnd, 1);
     HIPCHK(c, hipMemcpy(c->d_rnd, rnd, sizeof(rnd), hipMemcpyHostToDevice));
     long long lcg = 1; HIPCHK(c, hipMemcpy(c->d_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
@@ -305,6 +325,8 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
     if (c->d_trace) hipFree(c->d_trace);
     hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user);
+    hipFree(c->d_nb_nz); hipFree(c->d_nb_cbp); hipFree(c->d_nb_mvd); hipFree(c->d_cabac); hipFree(c->d_cabac_tab); hipFree(c->d_dbg_hash);
+    for (int q = 0; q < 52; q++) if (c->d_cabac_init[q]) hipFree(c->d_cabac_init[q]);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -323,6 +345,33 @@ static int ensure_qp(pcamv_ctx *c, int qp)
     }
     pcamv_frame_set_qp(&c->F, &c->p, qp);
     c->F.cost_mv = c->d_cost_mv[qp] + PCAMV_COST_MV_CENTRE;
+    if (c->F.b_mbrd) {          /* context states at the slice start for this QP (x264_cabac_context_init, encoder.c:1227) */
+        if (!c->d_cabac_init[qp]) {
+            uint8_t init[464];
+            pcamv_build_cabac_init(qp, init);
+            hipError_t e = dalloc(&c->d_cabac_init[qp], (size_t)464);
+            if (e == hipSuccess) e = hipMemcpy(c->d_cabac_init[qp], init, 464, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(c, PCAMV_EHIP, "context initialisation upload: %s", hipGetErrorString(e));
+        }
+        c->F.cabac_init = c->d_cabac_init[qp];
+    }
+    return 0;
+}
+/* diagnostics (parity tests): FNV-1a of the 460 CABAC context states after every macroblock of the following analyses */
+extern "C" int pcamv_gpu_debug_state_hash(pcamv_ctx_t *c, int enable)
+{
+    if (!c) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (enable && !c->d_dbg_hash) { HIPCHK(c, dalloc(&c->d_dbg_hash, (size_t)c->F.n_mb)); HIPCHK(c, hipMemset(c->d_dbg_hash, 0, (size_t)c->F.n_mb * 4)); }
+    c->F.dbg_hash = enable ? c->d_dbg_hash : NULL;
+    return 0;
+}
+extern "C" int pcamv_gpu_debug_state_hash_fetch(pcamv_ctx_t *c, uint32_t *out)
+{
+    if (!c || !out || !c->d_dbg_hash) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_dbg_hash, (size_t)c->F.n_mb * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -396,7 +445,8 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         if (b->sched_flow) {
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-            if (tesa) pcamv_launch_flow_tesa((unsigned)b->flow_waves, st, dF, b->fl);
+            if (F.b_mbrd) pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl);
+            else if (tesa) pcamv_launch_flow_tesa((unsigned)b->flow_waves, st, dF, b->fl);
             else hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
         } else {
@@ -465,6 +515,7 @@ extern "C" int pcamv_gpu_set_ref(pcamv_ctx_t *c, const uint8_t *const plane[3], 
         c->F.raw[i] = c->d_raw[i];
     }
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
+    c->F.ref_is_inter = prev_mv != NULL && prev_ref != NULL;      /* the reference picture is a P picture: its macroblock types (analyse.c:369) */
     c->prev_internal = 0;
     c->F.mv = c->d_mv; c->F.ref8 = c->d_ref8;
     c->F.prev_mv = c->d_prev_mv; c->F.prev_ref = c->d_prev_ref;
@@ -481,6 +532,7 @@ extern "C" int pcamv_gpu_set_ref_device(pcamv_ctx_t *c, const void *y, const voi
 {
     if (!c || !y || !u || !v) return PCAMV_EINVAL;
     c->F.have_prev = prev_mv != NULL && prev_ref != NULL && c->p.i_tscale != 0;
+    c->F.ref_is_inter = prev_mv != NULL && prev_ref != NULL;
     c->prev_internal = prev_mv == PCAMV_PREV_FIELD_INTERNAL;
     if (c->F.have_prev && !c->prev_internal) { c->F.prev_mv = (const int16_t *)prev_mv; c->F.prev_ref = (const int8_t *)prev_ref; c->F.mv = c->d_mv; c->F.ref8 = c->d_ref8; }
     /* the filter itself runs as the first kernels of the next step (plane production is part of the

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "pcamv_common.h"
+#include "pcamv_entropy_tables.h"
 
 static const int pcamv_lambda_tab[52] = {
     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
@@ -71,6 +72,28 @@ static inline void pcamv_frame_set_qp(FrameDev *F, const pcamv_params_t *p, int 
         F->dq_mf[cls] = pcamv_dequant_class_scale(qp % 6, cls);
         F->dq_mf_c[cls] = pcamv_dequant_class_scale(F->chroma_qp % 6, cls);
     }
+    /* --subme >= 6: lambda2 of the RD cost, the intra luma quantiser (CQM_4IY, common/set.c:77) of the 4x4 intra analysis */
+    F->lambda2 = pcamv_lambda2_tab[qp];
+    for (int cls = 0; cls < 3; cls++) {
+        int base = pcamv_quant_class_scale(qp % 6, cls), s = qp / 6 - 1, j;
+        j = s < 0 ? base << -s : s == 0 ? base : (base + (1 << (s - 1))) >> s;
+        int b1 = (((32 - p->i_luma_deadzone[1]) << 10) + (j >> 1)) / j, b2 = (1 << 15) / j;
+        F->q_mf_i[cls] = j; F->q_bias_i[cls] = b1 < b2 ? b1 : b2;
+    }
+}
+/* CABAC context states at the start of a P slice (common/cabac.c:787-805, cabac_init_idc 0) and the per-(state, bin)
+ * table the size-only coder walks: x264's 8.8 fixed-point entropy << 8 | next state (common/cabac.c:718-781) */
+static inline void pcamv_build_cabac_init(int qp, uint8_t *out /* [464] */)
+{
+    for (int i = 0; i < 460; i++) {
+        int v = ((pcamv_cabac_init_p[2 * i] * qp) >> 4) + pcamv_cabac_init_p[2 * i + 1];
+        out[i] = (uint8_t)(v < 1 ? 1 : v > 126 ? 126 : v);
+    }
+    out[460] = out[461] = out[462] = out[463] = 0;
+}
+static inline void pcamv_build_cabac_tab(uint32_t *out /* [256] */)
+{
+    for (int i = 0; i < 256; i++) out[i] = (uint32_t)pcamv_cabac_entropy[i] << 8 | pcamv_cabac_transition[i];
 }
 static inline void pcamv_frame_set_params(FrameDev *F, const pcamv_params_t *p)
 {
@@ -82,5 +105,7 @@ static inline void pcamv_frame_set_params(FrameDev *F, const pcamv_params_t *p)
     F->b_chroma_me = p->b_chroma_me && p->i_subpel_refine >= 5;     /* analyse.c:246-247 */
     F->b_fast_pskip = p->b_fast_pskip; F->b_dct_decimate = p->b_dct_decimate; F->b_cabac = p->b_cabac;
     F->inter = p->inter; F->tscale = p->i_tscale; F->chroma_qp_offset = p->i_chroma_qp_offset;
+    F->b_mbrd = p->i_subpel_refine >= 6;                              /* analyse.c:236 */
+    F->psy_rd = F->b_mbrd ? p->i_psy_rd : 0;                          /* encoder.c:513-515 */
 }
 #endif

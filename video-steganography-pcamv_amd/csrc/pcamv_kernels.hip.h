@@ -371,6 +371,8 @@ struct FlowDev {
     unsigned qbase[8], qcount[8];
     int n_gop, n_mb, mb_w, mb_h, fused, nq;      /* nq = 8: GOP g lives in queue g & 7 (XCD affinity); nq = 1: one queue */
     int unit;                 /* macroblocks of a row per task (second pass only; 1 by default); mb_w / n_mb above are in tasks */
+    int raster;               /* --subme >= 6 with CABAC: the slice's context states chain the macroblocks of a frame in raster order
+                               * (encoder.c:1900-1927, rdo.c:62), so a macroblock's only predecessor is the one coded before it */
 };
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FLOW_HEAD(q) (64 * (q))
@@ -383,7 +385,7 @@ static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
     unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= fl.total) return;
     int xy = (int)(i % (unsigned)fl.n_mb), x = xy % fl.mb_w, y = xy / fl.mb_w;
-    fl.dep[i] = (x > 0) + (y > 0);
+    fl.dep[i] = fl.raster ? (xy > 0) : (x > 0) + (y > 0);
     /* word i of the queue array is entry k of queue q; the first ngop(q) entries of each queue start out
      * published: macroblock 0 of the GOPs k * nq + q */
     int q = 0;
@@ -481,7 +483,9 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
          * have drained, the counters / queue entries may follow -- no agent-scope release (it would write back the
          * XCD's whole dirty L2 once per macroblock: measured 13.3 -> 19.9 M MB/s without it) */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
+        if (lane == 0 && fl.raster) {
+            if (xy + 1 < fl.n_mb) flow_done_one(fl, g & (fl.nq - 1), g * fl.n_mb + xy + 1, item + 1u);
+        } else if (lane == 0) {
             const int base = g * fl.n_mb, q = g & (fl.nq - 1);
             if (x + 1 < fl.mb_w) flow_done_one(fl, q, base + xy + 1, item + 1u);
             if (y + 1 < fl.mb_h) {
@@ -494,7 +498,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         if (MODE == 0 && fl.fused) {
             if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
             have_ticket = true;
-            mbk_rca_encode(F, &L, Ap, xy, 1);
+            mbk_rca_encode(F, &L, Ap, xy, 1, (TESA & 2) && F.b_mbrd);
         }
         PROF_ADD(3, t_r);
         if (MODE == 0) PROF_ADD(4, t_pop);
@@ -519,6 +523,17 @@ static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa
 }
 #endif
 void pcamv_launch_flow_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+/* ... and so does the instance with the RD mode decision of --subme 6 / 7 (csrc/pcamv_rd.hip) */
+#ifdef PCAMV_RD_TU
+static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_rd(const FrameDev *__restrict__ Fs, FlowDev fl)
+{
+    __shared__ MBLocal L;
+    __shared__ Analysis A;
+    flow_loop<0, 2>(Fs, fl, L, &A, nullptr);
+}
+#endif
+void pcamv_launch_flow_rd(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu(void);
 
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the

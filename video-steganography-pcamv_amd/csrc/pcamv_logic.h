@@ -110,7 +110,7 @@ PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
 
 /* lite: only what the reconstruction of a macroblock with known MVs needs (position, MV limits, source pixels) --
  * no neighbour types / motion, no skip prediction (second pass of a macroblock that is not P_SKIP) */
-PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int lite = 0)
+PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int lite = 0, int rd = 0)
 {
     L->mb_x = mb_x; L->mb_y = mb_y; L->mb_xy = mb_y * F.mb_w + mb_x;
     L->b_skip_mc = 0;
@@ -158,6 +158,7 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
     L->mv_min_fpel[1] = (L->mv_min_spel[1] >> 2) + 5;
     L->mv_max_fpel[1] = (L->mv_max_spel[1] >> 2) - 5;
     prim_load_fenc(F, L);
+    if (rd && !lite) prim_rd_load(F, L);            /* --subme >= 6: intra neighbours, entropy-coder neighbourhood, context states */
 }
 
 /* ---------------------------------------------------------------- motion search */
@@ -191,7 +192,10 @@ PCAMV_DEV EvalRes eval_cands(const FrameDev &F, MBLocal *L, MEState *me, const u
  * encoder.c mbcmp_init: with --me tesa and subme > 1 the "full-pel" comparisons of the search (fpelcmp: COST_MV,
  * COST_MV_HPEL, the half-pel rounds of refine_subpel) are SATD instead of SAD.  FPEL_LIST: flags of a list of full-pel
  * candidates, FPEL_SAD: flags of a quarter-pel list scored with that metric. */
-#define FPEL_SATD (TESA && F.me_method == PCAMV_ME_TESA && F.subme > 1)
+/* The template parameter is a variant mask: bit 0 = the --me tesa instance, bit 1 = the instance with the RD mode decision of
+ * --subme >= 6 compiled in (a kernel of its own as well: its code would otherwise cost the search kernel registers). */
+#define FPEL_SATD ((TESA & 1) && F.me_method == PCAMV_ME_TESA && F.subme > 1)
+#define MBRD_ON ((TESA & 2) && F.b_mbrd)
 #define FPEL_LIST (FPEL_SATD ? EV_SATD : EV_FPEL)
 #define FPEL_SAD (FPEL_SATD ? EV_SATD : 0)
 /* the n listed full-pel candidates folded into the running best, in list order (strict <) */
@@ -432,7 +436,7 @@ PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[
             EvalRes r = prim_esa_window(F, L, ip, me->xoff, me->yoff, min_x, min_y, width, max_y - min_y + 1, me->mvp[0], me->mvp[1]);
             if (r.cost < bcost) { bcost = r.cost; bmx = min_x + r.idx % width; bmy = min_y + r.idx / width; }
         }
-    } else if (TESA && F.me_method == PCAMV_ME_TESA) {
+    } else if ((TESA & 1) && F.me_method == PCAMV_ME_TESA) {
         tesa_search<TESA>(F, L, me, bmx, bmy, bcost, i_me_range, mv_x_min, mv_x_max, mv_y_min, mv_y_max);
     } else { /* UMH */
         int ucost1, ucost2, cross_start = 1, do_hex = 1, done = 0;
@@ -511,7 +515,9 @@ PCAMV_DEV void me_refine_qpel(const FrameDev &F, MBLocal *L, MEState *me)
 
 /* ---------------------------------------------------------------- macroblock (re-)encode */
 /* sequential-equivalent decimation of a 4x4 scan: done per block by prim_residual (blk_score) */
-PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L, int win = 0)
+/* lv: also leave the quantised levels in scan order (L->coef, L->cdc) and the per-block non-zero flags (L->nzc) for the
+ * entropy coder's size / context walk (--subme >= 6) */
+PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L, int win = 0, int lv = 0)
 {
     if (L->i_type == PCAMV_P_SKIP) {
         if (!L->b_skip_mc) {
@@ -524,7 +530,7 @@ PCAMV_DEV void mb_encode(const FrameDev &F, MBLocal *L, int win = 0)
         return;
     }
     if (!L->b_skip_mc) prim_predict_mb(F, L, win);
-    prim_mb_transform(F, L);
+    prim_mb_transform(F, L, lv);
 }
 
 PCAMV_DEV int probe_pskip(const FrameDev &F, MBLocal *L)
@@ -561,6 +567,7 @@ struct Analysis {
     MEState me4x4[4][4], me8x4[4][2], me4x8[4][2];
     int mvc[5][2];
     int cost8x8, cost16x8, cost8x16, cost4x4[4], cost8x4[4], cost4x8[4];
+    int rd16x16;
 };
 PCAMV_DEV void me_setup(MEState *me, int ip, int xoff, int yoff) { me->i_pixel = ip; me->xoff = xoff; me->yoff = yoff; me->cost = me->cost_mv = me->cost_rec = 0; me->mv[0] = me->mv[1] = 0; me->mvp[0] = me->mvp[1] = 0; }
 
@@ -593,6 +600,184 @@ PCAMV_DEV void update_cache(MBLocal *L, Analysis *a)
     }
 }
 
+/* ---------------------------------------------------------------- --subme >= 6: RD mode decision (i_mbrd = 1, analyse.c:236)
+ *   intra SATD analysis (only its cost enters, as a bound on the RD trials)   analyse.c:552-879
+ *   size-only CABAC walk of the macroblock layer / context adaptation       rdo.c:49-62, encoder/cabac.c:85-113, 234-330, 403-470, 777-1018
+ *   x264_rd_cost_mb, x264_mb_analyse_p_rd                                    rdo.c:139-171, analyse.c:2117-2186 */
+PCAMV_DEV int intra_avail(int nb) { return (nb & NB_TOPLEFT) ? 3 : (nb & NB_LEFT) ? 1 : (nb & NB_TOP) ? 2 : 0; }      /* bit 0: left, bit 1: top (predict_*_mode_available) */
+PCAMV_DEV int intra_chroma_cost(const FrameDev &F, MBLocal *L)
+{
+    prim_intra8c_satd(F, L, intra_avail(L->neighbour));      /* ccost[mode]: DC (its variant), H, V, P over both planes; COST_MAX = not available */
+    int best = PCAMV_COST_MAX;
+    for (int m = 0; m < 4; m++) {
+        const int c = L->ccost[m];
+        if (c < PCAMV_COST_MAX) best = imin(best, c + F.lambda * (m == 0 ? 1 : m == 3 ? 5 : 3));       /* lambda * bs_size_ue(mode) */
+    }
+    return best;
+}
+/* common/macroblock.c:765-774, 1226-1238: the neighbours 4x4 block i has */
+PCAMV_DEV int intra4_neighbours(int nb, int i)
+{
+    if (i == 0) return (nb & (NB_TOP | NB_LEFT | NB_TOPLEFT)) | ((nb & NB_TOP) ? NB_TOPRIGHT : 0);
+    if (i == 1 || i == 4) return NB_LEFT | ((nb & NB_TOP) ? (NB_TOP | NB_TOPLEFT | NB_TOPRIGHT) : 0);
+    if (i == 2 || i == 8 || i == 10) return NB_TOP | NB_TOPRIGHT | ((nb & NB_LEFT) ? (NB_LEFT | NB_TOPLEFT) : 0);
+    if (i == 5) return NB_LEFT | (nb & NB_TOPRIGHT) | ((nb & NB_TOP) ? (NB_TOP | NB_TOPLEFT) : 0);
+    return NB_LEFT | NB_TOP | NB_TOPLEFT | ((i == 3 || i == 7 || i == 11 || i == 13 || i == 15) ? 0 : NB_TOPRIGHT);
+}
+PCAMV_DEV int i4_fix(int m) { return m < 0 ? -1 : m > I4_HU ? I4_DC : m; }
+PCAMV_DEV void intra_analyse(const FrameDev &F, MBLocal *L, int i_satd_inter, int *i16, int *i4)
+{
+    *i16 = *i4 = PCAMV_COST_MAX;
+    prim_intra16_satd(F, L, intra_avail(L->neighbour));      /* ccost[mode]: V, H, DC (its variant), P */
+    for (int m = 0; m < 4; m++) {
+        const int c = L->ccost[m];
+        if (c < PCAMV_COST_MAX) *i16 = imin(*i16, c + F.lambda * (m == 0 ? 1 : m == 3 ? 5 : 3));
+    }
+    if (L->b_fast_intra && *i16 > 2 * i_satd_inter) return;
+    if (!(F.inter & PCAMV_ANALYSE_I4x4)) return;
+    int thresh = imin(i_satd_inter, *i16);
+    thresh = thresh * (10 - L->b_fast_intra) / 8;
+    int cost = F.lambda * 24, idx;
+    prim_intra4_init(L);
+    for (idx = 0;; idx++) {
+        const int n4 = intra4_neighbours(L->neighbour, idx);
+        const int fa = i4_fix(L->i4mode[scan8_of(idx) - 1]), fb = i4_fix(L->i4mode[scan8_of(idx) - 8]);
+        const int pred_mode = imin(fa, fb) < 0 ? I4_DC : imin(fa, fb);
+        int n = 0;
+        PCAMV_WAVE_SYNC();
+        if ((n4 & NB_LEFT) && (n4 & NB_TOP)) {
+            L->slots[n++] = I4_DC; L->slots[n++] = I4_H; L->slots[n++] = I4_V; L->slots[n++] = I4_DDL;
+            if (n4 & NB_TOPLEFT) { L->slots[n++] = I4_DDR; L->slots[n++] = I4_VR; L->slots[n++] = I4_HD; }
+            L->slots[n++] = I4_VL; L->slots[n++] = I4_HU;
+        } else if (n4 & NB_LEFT) { L->slots[n++] = I4_DC_LEFT; L->slots[n++] = I4_H; L->slots[n++] = I4_HU; }
+        else if (n4 & NB_TOP) { L->slots[n++] = I4_DC_TOP; L->slots[n++] = I4_V; L->slots[n++] = I4_DDL; L->slots[n++] = I4_VL; }
+        else L->slots[n++] = I4_DC_128;
+        prim_intra4_costs(F, L, idx, n, (n4 & (NB_TOPRIGHT | NB_TOP)) == NB_TOP);     /* ccost[i] = SATD of mode slots[i] */
+        int best = PCAMV_COST_MAX, best_mode = 0;
+        for (int i = 0; i < n; i++) {
+            const int c = L->ccost[i] + F.lambda * (pred_mode == i4_fix(L->slots[i]) ? 1 : 4);
+            if (c < best) { best = c; best_mode = L->slots[i]; }
+        }
+        cost += best;
+        if (cost > thresh || idx == 15) break;
+        prim_intra4_encode(F, L, idx, best_mode);
+        L->i4mode[scan8_of(idx)] = (int8_t)best_mode;
+    }
+    if (idx == 15) *i4 = cost;
+}
+
+/* one CABAC decision on the context states S (LDS): every lane walks the same chain.  Table word = bits (8.8) << 8 | next state */
+PCAMV_DEV void cb_dec(MBLocal *L, uint8_t *S, int ctx, int b, int *bits)
+{
+    const uint32_t w = L_CTAB(L)[2 * S[ctx] + b];
+    S[ctx] = (uint8_t)(w & 255u);
+    *bits += (int)(w >> 8);
+}
+PCAMV_DEV void cb_mvd_cpn(MBLocal *L, uint8_t *S, int idx, int l, int mvd, int *bits)      /* encoder/cabac.c:403-449 */
+{
+    const int amvd = iabs(L->cmvd[scan8_of(idx) - 1][l]) + iabs(L->cmvd[scan8_of(idx) - 8][l]);
+    const int a = iabs(mvd), base = l ? 47 : 40;
+    cb_dec(L, S, base + (amvd > 2) + (amvd > 32), a != 0, bits);
+    if (!a) return;
+    for (int i = 1; i < imin(a, 9); i++) cb_dec(L, S, base + imin(i + 2, 6), 1, bits);      /* contexts 3, 4, 5, 6, 6, .. */
+    if (a < 9) cb_dec(L, S, base + imin(a + 2, 6), 0, bits);
+    else *bits += (size_ue_of((unsigned)(a - 9 + 7)) - 3) << 8;                              /* Exp-Golomb k = 3 suffix, bypass */
+    *bits += 256;                                                                           /* sign, bypass */
+}
+PCAMV_DEV void cb_mvd(MBLocal *L, uint8_t *S, int idx, int width, int height, int *bits)     /* encoder/cabac.c:452-470 */
+{
+    int mvp[2];
+    predict_mv(L, idx, width, mvp);
+    const int dx = L->cmv[scan8_of(idx)][0] - mvp[0], dy = L->cmv[scan8_of(idx)][1] - mvp[1];
+    cb_mvd_cpn(L, S, idx, 0, dx, bits);
+    cb_mvd_cpn(L, S, idx, 1, dy, bits);
+    for (int j = 0; j < height; j++)
+        for (int i = 0; i < width; i++) { L->cmvd[scan8_of(idx) + i + 8 * j][0] = (int16_t)dx; L->cmvd[scan8_of(idx) + i + 8 * j][1] = (int16_t)dy; }
+}
+/* macroblock layer of a P_L0 / P_8x8 macroblock up to the residual: mb_type, sub_mb_type, mvd, coded_block_pattern,
+ * mb_qp_delta (0: constant QP, last delta 0).  Returns the bits in 8.8 fixed point. */
+PCAMV_DEV int cabac_mb_header(const FrameDev &F, MBLocal *L, uint8_t *S)
+{
+    int bits = 0;
+    cb_dec(L, S, 14, 0, &bits);
+    if (L->i_type == PCAMV_P_8x8 || L->i_partition == PCAMV_D_16x16) { cb_dec(L, S, 15, 0, &bits); cb_dec(L, S, 16, L->i_type == PCAMV_P_8x8, &bits); }
+    else { cb_dec(L, S, 15, 1, &bits); cb_dec(L, S, 17, L->i_partition == PCAMV_D_16x8, &bits); }
+    if (L->i_type == PCAMV_P_8x8) {
+        for (int i = 0; i < 4; i++) {
+            const int sp = L->sub_part[i];
+            cb_dec(L, S, 21, sp == PCAMV_D_L0_8x8, &bits);
+            if (sp != PCAMV_D_L0_8x8) { cb_dec(L, S, 22, sp != PCAMV_D_L0_8x4, &bits); if (sp != PCAMV_D_L0_8x4) cb_dec(L, S, 23, sp == PCAMV_D_L0_4x8, &bits); }
+        }
+        for (int i = 0; i < 4; i++)
+            switch (L->sub_part[i]) {
+            case PCAMV_D_L0_8x8: cb_mvd(L, S, 4 * i, 2, 2, &bits); break;
+            case PCAMV_D_L0_8x4: cb_mvd(L, S, 4 * i, 2, 1, &bits); cb_mvd(L, S, 4 * i + 2, 2, 1, &bits); break;
+            case PCAMV_D_L0_4x8: cb_mvd(L, S, 4 * i, 1, 2, &bits); cb_mvd(L, S, 4 * i + 1, 1, 2, &bits); break;
+            default: for (int k = 0; k < 4; k++) cb_mvd(L, S, 4 * i + k, 1, 1, &bits); break;
+            }
+    } else if (L->i_partition == PCAMV_D_16x16) cb_mvd(L, S, 0, 4, 4, &bits);
+    else if (L->i_partition == PCAMV_D_16x8) { cb_mvd(L, S, 0, 4, 2, &bits); cb_mvd(L, S, 8, 4, 2, &bits); }
+    else { cb_mvd(L, S, 0, 2, 4, &bits); cb_mvd(L, S, 4, 2, 4, &bits); }
+    const int cbp = L->cbp_luma, cl = L->cbp_left, ct = L->cbp_top;
+    cb_dec(L, S, 76 - ((cl >> 1) & 1) - ((ct >> 1) & 2), cbp & 1, &bits);
+    cb_dec(L, S, 76 - (cbp & 1) - ((ct >> 2) & 2), (cbp >> 1) & 1, &bits);
+    cb_dec(L, S, 76 - ((cl >> 3) & 1) - ((cbp << 1) & 2), (cbp >> 2) & 1, &bits);
+    cb_dec(L, S, 76 - ((cbp >> 2) & 1) - (cbp & 2), (cbp >> 3) & 1, &bits);
+    const int ca = cl & 0x30, cb = ct & 0x30;
+    cb_dec(L, S, 77 + ((ca && cl != -1) ? 1 : 0) + ((cb && ct != -1) ? 2 : 0), L->cbp_chroma != 0, &bits);
+    if (L->cbp_chroma) cb_dec(L, S, 77 + 4 + (ca == 0x20) + 2 * (cb == 0x20), L->cbp_chroma > 1, &bits);
+    if (L->cbp_luma | L->cbp_chroma) cb_dec(L, S, 60, 0, &bits);
+    (void)F;
+    return bits;
+}
+/* x264_rd_cost_mb (rdo.c:139-171) of the macroblock as the cache describes it: distortion (SSD + psy-RD) + lambda2 * bits */
+PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
+{
+    L->b_skip_mc = 0;
+    const unsigned long long t_e = PROF_T();
+    mb_encode(F, L, 0, 1);
+    PROF_ADD(18, t_e);
+    const unsigned long long t_s = PROF_T();
+    const int ssd = prim_ssd_mb(F, L);
+    PROF_ADD(19, t_s);
+    int bits;
+    if (F.b_cabac) {
+        const unsigned long long t_h = PROF_T();
+        prim_cabac_trial_begin(L);                           /* trial copy of the macroblock-header contexts */
+        int f8 = cabac_mb_header(F, L, L_CAB(L, 1));
+        PROF_ADD(20, t_h);
+        const unsigned long long t_r = PROF_T();
+        f8 += prim_cabac_residual(F, L, 0);
+        PROF_ADD(21, t_r);
+        bits = (int)(((unsigned long long)(unsigned)f8 * (unsigned long long)F.lambda2 + 32768ull) >> 16);
+    } else
+        bits = (int)((unsigned)prim_cavlc_mb(F, L) * (unsigned)F.lambda2 + 128u) >> 8;       /* int arithmetic in the reference */
+    return ssd + bits;
+}
+PCAMV_DEV void analyse_p_rd(const FrameDev &F, MBLocal *L, struct Analysis *a, int i_satd)
+{
+    const int thresh = i_satd * 5 / 4;
+    L->i_type = PCAMV_P_L0;
+    if (a->rd16x16 == PCAMV_COST_MAX && a->me16x16.cost <= i_satd * 3 / 2) { L->i_partition = PCAMV_D_16x16; update_cache(L, a); a->rd16x16 = rd_cost_mb(F, L); }
+    a->me16x16.cost = a->rd16x16;
+    if (a->cost16x8 <= thresh) { L->i_partition = PCAMV_D_16x8; update_cache(L, a); a->cost16x8 = rd_cost_mb(F, L); } else a->cost16x8 = PCAMV_COST_MAX;
+    if (a->cost8x16 <= thresh) { L->i_partition = PCAMV_D_8x16; update_cache(L, a); a->cost8x16 = rd_cost_mb(F, L); } else a->cost8x16 = PCAMV_COST_MAX;
+    if (a->cost8x8 <= thresh) { L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8; update_cache(L, a); a->cost8x8 = rd_cost_mb(F, L); } else a->cost8x8 = PCAMV_COST_MAX;
+}
+/* what the entropy coder leaves behind for the following macroblocks (encoder.c:1900-1927, common/macroblock.c:1254-1400):
+ * the context states adapted to the macroblock as coded, its non-zero flags / counts, coded block pattern and MV differences */
+PCAMV_DEV void entropy_commit(const FrameDev &F, MBLocal *L)
+{
+    const int skip = L->i_type == PCAMV_P_SKIP;
+    if (F.b_cabac) {
+        int bits = 0;
+        uint8_t *S = L_CAB(L, 0);
+        cb_dec(L, S, 11 + (L->type_left >= 0 && L->type_left != PCAMV_P_SKIP) + (L->type_top >= 0 && L->type_top != PCAMV_P_SKIP), skip, &bits);   /* x264_cabac_mb_skip */
+        if (!skip) { cabac_mb_header(F, L, S); prim_cabac_residual(F, L, 1); }
+    } else if (!skip) prim_cavlc_mb(F, L);
+    prim_rd_commit(F, L, skip);
+}
+
 template <int TESA>
 PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_try_pskip)
 {
@@ -614,6 +799,14 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
     L->mvr_own[0] = (int16_t)me.mv[0]; L->mvr_own[1] = (int16_t)me.mv[1];
     cache_ref_set(L, 0, 0, 4, 4, 0);
     L->i_type = PCAMV_P_L0;
+    if (MBRD_ON) {                                   /* analyse.c:1194-1203 */
+        prim_fenc_complexity(F, L);
+        if (me.mv[0] == L->pskip_mv[0] && me.mv[1] == L->pskip_mv[1]) {
+            L->i_partition = PCAMV_D_16x16;
+            cache_mv_set(L, 0, 0, 4, 4, me.mv[0], me.mv[1]);
+            a->rd16x16 = rd_cost_mb(F, L);
+        }
+    }
     return 0;
 }
 template <int TESA>
@@ -831,6 +1024,7 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
     const unsigned long long t_a = PROF_T();
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
     L->i_partition = PCAMV_D_16x16;
+    a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = PCAMV_COST_MAX;      /* analyse.c:321-332 */
     if (F.b_fast_pskip) {
         if (F.subme >= 3) b_try_pskip = 1;
         else if (L->type_left == PCAMV_P_SKIP || L->type_top == PCAMV_P_SKIP || L->type_topleft == PCAMV_P_SKIP || L->type_topright == PCAMV_P_SKIP)
@@ -873,6 +1067,26 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
         L->i_partition = i_partition;
         PROF_ADD(8, t_c);
         const unsigned long long t_d = PROF_T();
+        if (MBRD_ON) {
+            /* analyse.c:2749-2752, 2809-2850: no quarter-pel refinement; the intra SATD cost (never an intra mode: analyse.c:2863)
+             * bounds the RD trials; x264_rd_cost_mb decides the partition; P_8x8 only while embedding (analyse.c:2841) */
+            int i16, i4;
+            const unsigned long long t_i = PROF_T();
+            if (F.b_chroma_me) {
+                const int c8 = intra_chroma_cost(F, L);
+                intra_analyse(F, L, i_cost - c8, &i16, &i4);
+                i16 += c8; i4 += c8;
+            } else intra_analyse(F, L, i_cost, &i16, &i4);
+            PROF_ADD(16, t_i);
+            const unsigned long long t_rd = PROF_T();
+            analyse_p_rd(F, L, a, imin(i_cost, imin(i16, i4)));
+            PROF_ADD(17, t_rd);
+            i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x16; i_cost = a->me16x16.cost;
+            if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = PCAMV_D_16x8; }
+            if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_partition = PCAMV_D_8x16; }
+            if (F.embed && a->cost8x8 < i_cost) { i_cost = a->cost8x8; i_partition = PCAMV_D_8x8; i_type = PCAMV_P_8x8; }
+            L->i_partition = i_partition;
+        } else
         if (i_partition == PCAMV_D_16x16) me_refine_qpel<TESA>(F, L, &a->me16x16);
         else if (i_partition == PCAMV_D_16x8) { me_refine_qpel<TESA>(F, L, &a->me16x8[0]); me_refine_qpel<TESA>(F, L, &a->me16x8[1]); }
         else if (i_partition == PCAMV_D_8x16) { me_refine_qpel<TESA>(F, L, &a->me8x16[0]); me_refine_qpel<TESA>(F, L, &a->me8x16[1]); }

@@ -24,9 +24,24 @@ template <int TESA>
 PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
 {
     const unsigned long long t_l = PROF_T();
-    mb_load(F, L, mb_x, mb_y);
+    mb_load(F, L, mb_x, mb_y, 0, MBRD_ON);
     PROF_ADD(11, t_l);
     analyse_mb_search<TESA>(F, L, a);
+    if (MBRD_ON) {
+        /* --subme >= 6: the macroblock as coded is part of what its neighbours read (reconstructed pixels for the intra
+         * thresholds, non-zero flags / coded block pattern / MV differences / context states for the bit counts), so the
+         * pass-1 reconstruction and the entropy coder's bookkeeping come before the hand-off */
+        const unsigned long long t_c = PROF_T();
+        L->b_skip_mc = 0;
+        mb_encode(F, L, 0, 1);
+#ifdef PCAMV_HOST_EMU
+        prim_store_rec(F, L);
+#else
+        prim_store_rec(F, L, true);
+#endif
+        entropy_commit(F, L);
+        PROF_ADD(22, t_c);
+    }
     const unsigned long long t_w = PROF_T();
     const int xy = L->mb_xy;
     int *slots = L->slots;
@@ -106,7 +121,7 @@ PCAMV_DEV void mbk_rca(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int k
 /* fused = this wave has just searched this macroblock (dataflow schedule): MBLocal and Analysis still hold what
  * analysis_from_record would rebuild from the record (neighbour cache, limits, source pixels, decided MVs in the cache,
  * the carriers' search states), so only the fields that call resets are reset */
-PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0)
+PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0, int have_rec = 0)
 {
     const unsigned long long t_e = PROF_T();
     int n;
@@ -114,6 +129,7 @@ PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int 
         L->b_skip_mc = 0;
         n = carrier_slots(L->i_type, L->i_partition, L->sub_part, L->i_type != PCAMV_P_SKIP, L->slots);
         for (int k = 0; k < n; k++) { MEState *me = slot_me(L, a, L->slots[k]); me->cost = me->cost_mv = me->cost_rec = 0; }
+        if (have_rec) { PROF_ADD(10, t_e); return n; }      /* the search phase has reconstructed and stored the macroblock already (L->pred) */
     } else {
         n = analysis_from_record(F, L, a, xy, L->slots);
         update_cache(L, a);
@@ -148,9 +164,9 @@ PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, i
         }
     }
 }
-PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0)
+PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0, int have_rec = 0)
 {
-    mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy, fused));
+    mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy, fused, have_rec));
 }
 
 /* pass 2 of one macroblock (analyse.c:2870-3107 + x264_macroblock_encode, semantics of DESIGN.md 5b): the

@@ -633,7 +633,7 @@ __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L
  * (px,py) of the fenc/pred buffers (dct.c:122-170 sub4x4_dct, quant.c:33-109, 203-239).  d[] returns the
  * DEquantised levels (all zero when nothing survives), *rawdc the unquantised DC (chroma: its DC goes
  * through the 2x2 transform instead and d[0] is cleared before quantisation). */
-__device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+__device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc, int16_t *lv_out = nullptr)
 {
     *rawdc = d[0];
     if (!is_l) d[0] = 0;
@@ -655,6 +655,11 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
         big |= (unsigned)(c + 1) > 2u;
     }
     const int nz = zm != 0;
+    if (lv_out && nz) {       /* the quantised levels in scan order (h->dct.luma4x4), for the entropy coder's size walk */
+        constexpr int zz[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) *(uint32_t *)(lv_out + k) = (uint32_t)(uint16_t)d[zz[k]] | (uint32_t)(uint16_t)d[zz[k + 1]] << 16;
+    }
     /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC
      * ones for chroma): 9 as soon as a level exceeds 1, else the run-length table summed over the
      * non-zero levels, walked from the top of the mask */
@@ -680,7 +685,7 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
     *nz_out = nz; *score_out = score;
 }
 /* forward transform of the lane's 4x4 block at (px,py): fenc minus the prediction buffer pred (dct.c:122-170) */
-__device__ __forceinline__ void residual_block_at(const FrameDev &F, MBLocal *L, const uint8_t *pred, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+__device__ __forceinline__ void residual_block_at(const FrameDev &F, MBLocal *L, const uint8_t *pred, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc, int16_t *lv_out = nullptr)
 {
     int t[4][4];
 #pragma unroll
@@ -696,11 +701,11 @@ __device__ __forceinline__ void residual_block_at(const FrameDev &F, MBLocal *L,
         int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
         d[i * 4 + 0] = (int16_t)(s03 + s12); d[i * 4 + 1] = (int16_t)(2 * d03 + d12); d[i * 4 + 2] = (int16_t)(s03 - s12); d[i * 4 + 3] = (int16_t)(d03 - 2 * d12);
     }
-    quant_score_dequant(F, is_l, d, nz_out, score_out, rawdc);
+    quant_score_dequant(F, is_l, d, nz_out, score_out, rawdc, lv_out);
 }
-__device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc)
+__device__ __forceinline__ void residual_block(const FrameDev &F, MBLocal *L, int px, int py, bool is_l, int16_t d[16], int *nz_out, int *score_out, int *rawdc, int16_t *lv_out = nullptr)
 {
-    residual_block_at(F, L, L->pred, px, py, is_l, d, nz_out, score_out, rawdc);
+    residual_block_at(F, L, L->pred, px, py, is_l, d, nz_out, score_out, rawdc, lv_out);
 }
 /* one 4x4 block per lane into LDS (lanes 0..15 luma blocks in x264 block order, 16..19 U, 20..23 V):
  * the form the P_SKIP probe's wave-uniform checks read */
@@ -804,9 +809,12 @@ __device__ __forceinline__ int quad_had2x2(int v, int q)
  * 20..23 V), levels stay in registers, every decision is a quad / row DPP reduction:
  *   - the reference's saturating `if (dec8 < 6) dec8 += score` only ever compares against 4 and 6, so
  *     plain sums decide identically. */
-__device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
+/* lv: also leave the quantised levels in scan order (L->coef per block, L->cdc chroma DC in zigzag_scan_2x2_dc order) and the
+ * per-block non-zero flags as the entropy coder sees them (L->nzc: zero where an 8x8 / the macroblock / a chroma plane was dropped) */
+__device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L, int lv_ = 0)
 {
     PCAMV_WAVE_SYNC();
+    const int lv = rfl(lv_);
     const int lane = LANE();
     const bool is_l = lane < 16, is_c = lane >= 16 && lane < 24;
     const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
@@ -814,7 +822,7 @@ __device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
     const int py = is_l ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
     int16_t d[16];
     int nz = 0, score = 0, rawdc = 0;
-    if (is_l || is_c) residual_block(F, L, px, py, is_l, d, &nz, &score, &rawdc);
+    if (is_l || is_c) residual_block(F, L, px, py, is_l, d, &nz, &score, &rawdc, lv ? L->coef[lane < 24 ? lane : 0] : nullptr);
     /* luma: 8x8 sums over quads, macroblock sum over the row of 16 lanes */
     const int sc = (nz && F.b_dct_decimate) ? score : 0;
     int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8);
@@ -850,7 +858,18 @@ __device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L)
     }
     L->nnz_mask = (int)(__ballot(is_l && keep && nz) & 0xffffu);
     L->cbp_luma = (int)((keep_mask & 1) | ((keep_mask >> 3) & 2) | ((keep_mask >> 6) & 4) | ((keep_mask >> 9) & 8));
-    L->cbp_chroma = ac_mask ? 2 : 0;
+    const unsigned long long dc_mask = __ballot(is_c && nzdc);
+    L->cbp_chroma = ac_mask ? 2 : dc_mask ? 1 : 0;                 /* encoder/macroblock.c:364-372: DC-only chroma */
+    if (lv) {
+        if (is_l) L->nzc[scan8_of(lane)] = (uint8_t)(keep && nz);
+        else if (is_c) {
+            L->nzc[scan8_all_of(lane)] = (uint8_t)(cmode == 2 && nz);
+            const int q = lane & 3;
+            L->cdc[ch][q == 1 ? 2 : q == 2 ? 1 : q] = (int16_t)dcq;     /* zigzag_scan_2x2_dc: d[0][0], d[1][0], d[0][1], d[1][1] */
+            if (q == 0) L->nzc[scan8_all_of(25 + ch)] = (uint8_t)(nzdc != 0);
+        }
+        if (lane == 0) L->nzc[scan8_all_of(24)] = 0;
+    }
     PCAMV_WAVE_SYNC();
 }
 /* ---- four re-encodes of a 16x16 macroblock at once (RCA step, reference pixels in the LDS window) ---- */
@@ -970,4 +989,6 @@ __device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, in
 {
     if (LANE() == 0) NB_ST32(&F.mvr[2 * L->mb_xy], NB_PACK16(mvx, mvy));
 }
+PCAMV_DEV void predict_mv(MBLocal *L, int idx, int width, int mvp[2]);      /* pcamv_logic.h */
+#include "pcamv_prims_rd_gpu.h"
 #endif

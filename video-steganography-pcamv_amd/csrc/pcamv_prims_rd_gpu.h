@@ -1,0 +1,630 @@
+/*
+ * pcamv_prims_rd_gpu.h -- lane-parallel primitives of the RD mode decision (--subme 6 / 7), one wavefront = one macroblock.
+ *
+ *   intra SATD analysis     common/predict.c (16x16: 4 modes x 16 blocks = 64 lanes; chroma: 4 modes x 2 planes x 4 blocks;
+ *                           4x4: one mode per lane), encoder/macroblock.c:116-148 (the 4x4 blocks' own reconstruction)
+ *   psy-RD / SSD            encoder/rdo.c:65-137, encoder/analyse.c:522-549, common/pixel.c:256-358: 4x4 Hadamard per lane,
+ *                           the 8x8 transform as a 2x2 Hadamard across the four lanes of a quad
+ *   CABAC size walk         encoder/cabac.c:540-667: per block the significance map is one decision per lane (the lane that
+ *                           owns scan position i keeps the states of "significant[i]" / "last[i]" in registers across the
+ *                           blocks of a category), the level chain runs over the non-zero levels only, each decision on the
+ *                           lane that owns that level context
+ *   CAVLC size              encoder/cavlc.c:109-199: one block per lane
+ */
+#ifndef PCAMV_PRIMS_RD_GPU_H
+#define PCAMV_PRIMS_RD_GPU_H
+
+__device__ __forceinline__ uint32_t rep4(int v) { return (uint32_t)(v & 255) * 0x01010101u; }
+__device__ __forceinline__ int bsum4(uint32_t v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
+
+/* neighbourhood of a macroblock for the RD decision: intra prediction borders (unfiltered pass-1 reconstruction of the
+ * neighbours), entropy-coder context inputs (non-zero flags / counts, coded block patterns, MV differences), CABAC states */
+__device__ __forceinline__ void prim_rd_load(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    const int xy = L->mb_xy, top = xy - F.mb_w, nb = L->neighbour;
+    if (lane < 48) { L->nzc[lane] = 0; L->i4mode[lane] = -1; ((uint32_t *)L->cmvd)[lane] = 0; }
+    PCAMV_WAVE_SYNC();
+    if (lane < 16) {
+        const int k = lane & 7, is_left = lane >> 3;
+        /* cache positions of the bottom row / right column entries: 4 luma, 2 Cb, 2 Cr */
+        const int pos = is_left ? (k < 4 ? 3 + 8 * (1 + k) : k < 6 ? 0 + 8 * (1 + (k - 4)) : 0 + 8 * (4 + (k - 6)))
+                                : (k < 4 ? 4 + k : k < 6 ? 1 + (k - 4) : 1 + (k - 6) + 3 * 8);
+        const int avail = is_left ? (nb & NB_LEFT) : (nb & NB_TOP);
+        uint8_t v = 0x80;
+        if (avail) v = (uint8_t)NB_LD8(&F.nb_nz[(is_left ? xy - 1 : top) * 16 + 8 * is_left + k]);
+        L->nzc[pos] = v;
+    } else if (lane < 24) {
+        const int k = lane - 16, is_left = k >> 2, j = k & 3;
+        const int avail = is_left ? (nb & NB_LEFT) : (nb & NB_TOP);
+        if (avail) {
+            const int pos = is_left ? SCAN8_0 - 1 + 8 * j : SCAN8_0 - 8 + j;
+            ((uint32_t *)L->cmvd)[pos] = NB_LD32(&F.nb_mvd[((is_left ? xy - 1 : top) * 8 + k) * 2]);
+            L->i4mode[pos] = 2;                                  /* inter neighbours count as DC (common/macroblock.c:1282) */
+        }
+    } else if (lane == 24) L->cbp_top = (nb & NB_TOP) ? (int)(int16_t)NB_LD16(&F.nb_cbp[top]) : -1;
+    else if (lane == 25) L->cbp_left = (nb & NB_LEFT) ? (int)(int16_t)NB_LD16(&F.nb_cbp[xy - 1]) : -1;
+    else if (lane == 26) L->b_fast_intra = xy > 4 && F.ref_is_inter;          /* analyse.c:363-378 */
+    /* borders: luma 25 + 16, chroma 2 x (9 + 8) = 75 bytes, agent-scope loads (the neighbours stored them write-through) */
+    for (int i = lane; i < 75; i += 64) {
+        int c, is_left, k;
+        if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
+        else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
+        const int w = c ? 8 : 16, pw = c ? F.w >> 1 : F.w, x0 = L->mb_x * w, y0 = L->mb_y * w;
+        const uint8_t *pl = c == 0 ? F.rec[0] : c == 1 ? F.rec[1] : F.rec[2];
+        uint8_t v = 0;
+        if (is_left) { if (L->mb_x > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 + k) * pw + x0 - 1); L->ib_left[c][k] = v; }
+        else { if (L->mb_y > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 - 1) * pw + clip3i(x0 + k, 0, pw - 1)); L->ib_top[c][4 + k] = v; }
+    }
+    if (F.b_cabac) {
+        const uint32_t *src = (const uint32_t *)(xy == 0 ? F.cabac_init : F.cabac);
+        uint32_t *dst = (uint32_t *)L_CAB(L, 0);
+        if (xy == 0) { dst[lane] = src[lane]; if (lane < 52) dst[64 + lane] = src[64 + lane]; }
+        else { dst[lane] = NB_LD32(src + lane); if (lane < 52) dst[64 + lane] = NB_LD32(src + 64 + lane); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) L_CTAB(L)[64 * k + lane] = F.cabac_tab[64 * k + lane];
+    }
+    PCAMV_WAVE_SYNC();
+}
+
+/* ---------------------------------------------------------------- intra prediction SATD */
+/* 16x16: lane = mode * 16 + block (raster); modes V, H, DC (the variant the neighbours allow), P.  avail: bit 0 left, bit 1 top */
+__device__ __forceinline__ void prim_intra16_satd(const FrameDev &F, MBLocal *L, int avail_)
+{
+    const int avail = rfl(avail_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    const uint8_t *top = L->ib_top[0] + 4, *left = L->ib_left[0];
+    /* sums for DC (lanes 0..15 top, 16..31 left) and the plane gradients (lanes 32..39 H, 40..47 V) */
+    int v = 0;
+    if (lane < 16) v = top[lane];
+    else if (lane < 32) v = left[lane - 16];
+    else if (lane < 48) {
+        const int i = (lane & 7) + 1, isv = (lane >> 3) & 1;
+        const int hi = isv ? left[7 + i] : top[7 + i], lo = (7 - i < 0) ? top[-1] : isv ? left[7 - i] : top[7 - i];
+        v = i * (hi - lo);
+    }
+    const int s16 = group_sum(v, 16), s8 = group_sum(v, 8);
+    const int st = __builtin_amdgcn_readlane(s16, 0), sl = __builtin_amdgcn_readlane(s16, 16);
+    const int H = __builtin_amdgcn_readlane(s8, 32), V = __builtin_amdgcn_readlane(s8, 40);
+    const int dc = avail == 3 ? (st + sl + 16) >> 5 : avail == 1 ? (sl + 8) >> 4 : avail == 2 ? (st + 8) >> 4 : 128;
+    const int mode = lane >> 4, blk = lane & 15, px = 4 * (blk & 3), py = 4 * (blk >> 2);
+    uint32_t r[4], e[4], ec[8];
+    if (mode == 0) { const uint32_t t4 = lds4(top + px); r[0] = r[1] = r[2] = r[3] = t4; }
+    else if (mode == 1) { r[0] = rep4(left[py]); r[1] = rep4(left[py + 1]); r[2] = rep4(left[py + 2]); r[3] = rep4(left[py + 3]); }
+    else if (mode == 2) { r[0] = r[1] = r[2] = r[3] = rep4(dc); }
+    else {
+        const int a = 16 * (left[15] + top[15]), b = (5 * H + 32) >> 6, c = (5 * V + 32) >> 6;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + b * (px + x - 7) + c * (py + y - 7) + 16) >> 5, 0, 255) << (8 * x);
+            r[y] = o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + (py + k) * 16 + px);
+    int cost;
+    if (F.subme > 1) { pk_cols(e, ec); cost = satd4x4_half(ec, r); }
+    else { uint32_t sa = 0; for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa); cost = (int)sa; }
+    cost = group_sum(cost, 16);
+    const int need = mode == 0 ? 2 : mode == 1 ? 1 : mode == 3 ? 3 : 0;
+    if (blk == 0) L->ccost[mode] = (avail & need) == need ? cost : PCAMV_COST_MAX;
+    PCAMV_WAVE_SYNC();
+}
+/* chroma 8x8: lane = mode * 8 + plane * 4 + block; modes DC (variant), H, V, P; the cost of a mode is over both planes */
+__device__ __forceinline__ void prim_intra8c_satd(const FrameDev &F, MBLocal *L, int avail_)
+{
+    const int avail = rfl(avail_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    int cost = 0;
+    const int mode = (lane >> 3) & 3, plane = (lane >> 2) & 1, blk = lane & 3, px = 4 * (blk & 1), py = 4 * (blk >> 1);
+    if (lane < 32) {
+        const uint8_t *top = L->ib_top[1 + plane] + 4, *left = L->ib_left[1 + plane];
+        uint32_t r[4], e[4], ec[8];
+        if (mode == 2) { const uint32_t t4 = lds4(top + px); r[0] = r[1] = r[2] = r[3] = t4; }
+        else if (mode == 1) { r[0] = rep4(left[py]); r[1] = rep4(left[py + 1]); r[2] = rep4(left[py + 2]); r[3] = rep4(left[py + 3]); }
+        else if (mode == 0) {
+            const int s0 = bsum4(lds4(top)), s1 = bsum4(lds4(top + 4));
+            const int s2 = left[0] + left[1] + left[2] + left[3], s3 = left[4] + left[5] + left[6] + left[7];
+            int dc;
+            if (avail == 3) dc = blk == 0 ? (s0 + s2 + 4) >> 3 : blk == 1 ? (s1 + 2) >> 2 : blk == 2 ? (s3 + 2) >> 2 : (s1 + s3 + 4) >> 3;
+            else if (avail == 1) dc = blk < 2 ? (s2 + 2) >> 2 : (s3 + 2) >> 2;
+            else if (avail == 2) dc = (blk & 1) ? (s1 + 2) >> 2 : (s0 + 2) >> 2;
+            else dc = 128;
+            r[0] = r[1] = r[2] = r[3] = rep4(dc);
+        } else {
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 1; i <= 4; i++) { H += i * (top[3 + i] - top[3 - i]); V += i * ((int)left[3 + i] - (3 - i < 0 ? (int)top[-1] : (int)left[3 - i])); }
+            const int a = 16 * (left[7] + top[7]), b = (17 * H + 16) >> 5, c = (17 * V + 16) >> 5;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t o = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + b * (px + x - 3) + c * (py + y - 3) + 16) >> 5, 0, 255) << (8 * x);
+                r[y] = o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + 256 + (py + k) * 16 + plane * 8 + px);
+        if (F.subme > 1) { pk_cols(e, ec); cost = satd4x4_half(ec, r); }
+        else { uint32_t sa = 0; for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa); cost = (int)sa; }
+    }
+    cost = group_sum(cost, 8);
+    const int need = mode == 1 ? 1 : mode == 2 ? 2 : mode == 3 ? 3 : 0;
+    if (lane < 32 && (lane & 7) == 0) L->ccost[mode] = (avail & need) == need ? cost : PCAMV_COST_MAX;
+    PCAMV_WAVE_SYNC();
+}
+/* the 4x4 analysis works in a picture of its own (L_IFD: 17 rows of 32, row -1 / column -1 = the neighbours) */
+__device__ __forceinline__ void prim_intra4_init(MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    if (lane < 25) IFD(L, lane - 1, -1) = L->ib_top[0][3 + lane];
+    else if (lane < 41) IFD(L, -1, lane - 25) = L->ib_left[0][lane - 25];
+    PCAMV_WAVE_SYNC();
+}
+#define PF1(a, b) (((a) + (b) + 1) >> 1)
+#define PF2(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
+/* H.264 8.3.1.2 as common/predict.c:345-487 computes it: the 4x4 prediction of `mode` at (bx, by) of the analysis picture */
+__device__ __forceinline__ void ipred4_rows(const MBLocal *L, int bx, int by, int mode, uint32_t r[4])
+{
+    const uint8_t *base = L_IFD(L) + by * 32 + bx + 4;           /* row by - 1 */
+    const uint32_t t0 = lds4(base), t1 = lds4(base + 4);
+    int t[8], l[4], e[9];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { t[i] = (int)(t0 >> (8 * i) & 255); t[4 + i] = (int)(t1 >> (8 * i) & 255); l[i] = base[(i + 1) * 32 - 1]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { e[3 - i] = l[i]; e[5 + i] = t[i]; }
+    e[4] = base[-1];
+    int p[4][4];
+    switch (mode) {
+    case I4_V: r[0] = r[1] = r[2] = r[3] = t0; return;
+    case I4_H: r[0] = rep4(l[0]); r[1] = rep4(l[1]); r[2] = rep4(l[2]); r[3] = rep4(l[3]); return;
+    case I4_DC: r[0] = r[1] = r[2] = r[3] = rep4((l[0] + l[1] + l[2] + l[3] + t[0] + t[1] + t[2] + t[3] + 4) >> 3); return;
+    case I4_DC_LEFT: r[0] = r[1] = r[2] = r[3] = rep4((l[0] + l[1] + l[2] + l[3] + 2) >> 2); return;
+    case I4_DC_TOP: r[0] = r[1] = r[2] = r[3] = rep4((t[0] + t[1] + t[2] + t[3] + 2) >> 2); return;
+    case I4_DC_128: r[0] = r[1] = r[2] = r[3] = 0x80808080u; return;
+    case I4_DDL:
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) p[y][x] = (x == 3 && y == 3) ? PF2(t[6], t[7], t[7]) : PF2(t[x + y], t[x + y + 1], t[x + y + 2]);
+        break;
+    case I4_DDR:
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) p[y][x] = PF2(e[3 + x - y], e[4 + x - y], e[5 + x - y]);
+        break;
+    case I4_VR:
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int z = 2 * x - y, c = 4 + x - (y >> 1);
+                p[y][x] = z < -1 ? PF2(e[4 - y], e[5 - y], e[6 - y]) : (z & 1) ? PF2(e[c - 1], e[c], e[c + 1]) : PF1(e[c], e[c + 1]);
+            }
+        break;
+    case I4_HD:
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int z = 2 * y - x, q = y - (x >> 1);
+                p[y][x] = z < -1 ? PF2(e[2 + x], e[3 + x], e[4 + x]) : (z & 1) ? PF2(e[5 - q], e[4 - q], e[3 - q]) : PF1(e[4 - q], e[3 - q]);
+            }
+        break;
+    case I4_VL:
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) { const int k = x + (y >> 1); p[y][x] = (y & 1) ? PF2(t[k], t[k + 1], t[k + 2]) : PF1(t[k], t[k + 1]); }
+        break;
+    default:    /* I4_HU */
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int z = x + 2 * y, q = y + (x >> 1);
+                p[y][x] = z > 5 ? l[3] : z == 5 ? PF2(l[2], l[3], l[3]) : (z & 1) ? PF2(l[q], l[q + 1], l[q + 2]) : PF1(l[q], l[q + 1]);
+            }
+        break;
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) r[y] = (uint32_t)p[y][0] | (uint32_t)p[y][1] << 8 | (uint32_t)p[y][2] << 16 | (uint32_t)p[y][3] << 24;
+}
+/* SATD of the n listed modes (L->slots) of block idx, one mode per lane -> L->ccost[i] */
+__device__ __forceinline__ void prim_intra4_costs(const FrameDev &F, MBLocal *L, int idx_, int n_, int emulate_)
+{
+    const int idx = rfl(idx_), n = rfl(n_), emulate = rfl(emulate_);
+    const int lane = LANE();
+    const int bx = 4 * blk_x_of(idx), by = 4 * blk_y_of(idx);
+    PCAMV_WAVE_SYNC();
+    if (emulate) { *(uint32_t *)&IFD(L, bx + 4, by - 1) = rep4(IFD(L, bx + 3, by - 1)); PCAMV_WAVE_SYNC(); }     /* missing top right samples (analyse.c:812-814) */
+    if (lane < n) {
+        uint32_t r[4], e[4], ec[8];
+        ipred4_rows(L, bx, by, L->slots[lane], r);
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + (by + k) * 16 + bx);
+        int cost;
+        if (F.subme > 1) { pk_cols(e, ec); cost = satd4x4_half(ec, r); }
+        else { uint32_t sa = 0; for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa); cost = (int)sa; }
+        L->ccost[lane] = cost;
+    }
+    PCAMV_WAVE_SYNC();
+}
+/* x264_mb_encode_i4x4 (encoder/macroblock.c:116-148): the block's reconstruction replaces it in the analysis picture */
+__device__ __forceinline__ void prim_intra4_encode(const FrameDev &F, MBLocal *L, int idx_, int mode_)
+{
+    const int idx = rfl(idx_), mode = rfl(mode_);
+    const int bx = 4 * blk_x_of(idx), by = 4 * blk_y_of(idx);
+    PCAMV_WAVE_SYNC();
+    uint32_t r[4];
+    ipred4_rows(L, bx, by, mode, r);
+    int t[4][4], d[16];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t e = lds4(L->fenc + (by + y) * 16 + bx), p = r[y];
+        const int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
+        const int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
+        const int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
+        t[0][y] = s03 + s12; t[1][y] = 2 * d03 + d12; t[2][y] = s03 - s12; t[3][y] = d03 - 2 * d12;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+        d[i * 4 + 0] = s03 + s12; d[i * 4 + 1] = 2 * d03 + d12; d[i * 4 + 2] = s03 - s12; d[i * 4 + 3] = d03 - 2 * d12;
+    }
+    int nz = 0;
+    const int qbits = F.qp / 6 - 4;
+    int16_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int cls = (i & 1) + ((i >> 2) & 1);
+        const int mf = cls == 0 ? F.q_mf_i[0] : cls == 1 ? F.q_mf_i[1] : F.q_mf_i[2], bias = cls == 0 ? F.q_bias_i[0] : cls == 1 ? F.q_bias_i[1] : F.q_bias_i[2];
+        const int dq = cls == 0 ? F.dq_mf[0] : cls == 1 ? F.dq_mf[1] : F.dq_mf[2];
+        int v = d[i];
+        v = v > 0 ? ((bias + v) * mf >> 16) : -((bias - v) * mf >> 16);
+        nz |= v;
+        c[i] = qbits >= 0 ? (int16_t)((v * dq) << qbits) : (int16_t)((v * dq + (1 << (-qbits - 1))) >> (-qbits));
+    }
+    if (nz) {
+        /* add4x4_idct (dct.c:174-216) on top of the prediction rows */
+        int16_t tt[4][4], rr[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int s02 = c[0 * 4 + i] + c[2 * 4 + i], d02 = c[0 * 4 + i] - c[2 * 4 + i];
+            const int s13 = c[1 * 4 + i] + (c[3 * 4 + i] >> 1), d13 = (c[1 * 4 + i] >> 1) - c[3 * 4 + i];
+            tt[i][0] = (int16_t)(s02 + s13); tt[i][1] = (int16_t)(d02 + d13); tt[i][2] = (int16_t)(d02 - d13); tt[i][3] = (int16_t)(s02 - s13);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int s02 = tt[0][i] + tt[2][i], d02 = tt[0][i] - tt[2][i];
+            const int s13 = tt[1][i] + (tt[3][i] >> 1), d13 = (tt[1][i] >> 1) - tt[3][i];
+            rr[0][i] = (int16_t)((s02 + s13 + 32) >> 6); rr[1][i] = (int16_t)((d02 + d13 + 32) >> 6);
+            rr[2][i] = (int16_t)((d02 - d13 + 32) >> 6); rr[3][i] = (int16_t)((s02 - s13 + 32) >> 6);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((r[y] >> (8 * x)) & 255) + rr[y][x], 0, 255) << (8 * x);
+            r[y] = o;
+        }
+    }
+    PCAMV_WAVE_SYNC();
+    if (LANE() == 0) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) *(uint32_t *)&IFD(L, bx, by + y) = r[y];
+    }
+    PCAMV_WAVE_SYNC();
+}
+
+/* ---------------------------------------------------------------- psy-RD complexity + SSD */
+/* 4x4 Hadamard coefficients of the pixel rows (against zero) */
+__device__ __forceinline__ void had4x4_coefs(const uint32_t r[4], int t[16])
+{
+    int h[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const int p0 = (int)(r[y] & 255), p1 = (int)((r[y] >> 8) & 255), p2 = (int)((r[y] >> 16) & 255), p3 = (int)(r[y] >> 24);
+        const int s01 = p0 + p1, d01 = p0 - p1, s23 = p2 + p3, d23 = p2 - p3;
+        h[y][0] = s01 + s23; h[y][1] = d01 + d23; h[y][2] = s01 - s23; h[y][3] = d01 - d23;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int s01 = h[0][x] + h[1][x], d01 = h[0][x] - h[1][x], s23 = h[2][x] + h[3][x], d23 = h[2][x] - h[3][x];
+        t[x] = s01 + s23; t[4 + x] = d01 + d23; t[8 + x] = s01 - s23; t[12 + x] = d01 - d23;
+    }
+}
+/* lane < 16 (x264 block order: quads of lanes are 8x8 blocks): sum of |4x4 coefficients| of its block, its pixel sum, and
+ * its share of the sum of |8x8 coefficients| of its 8x8 (the 8x8 Hadamard = 2x2 Hadamard across the four 4x4 transforms) */
+__device__ __forceinline__ void had_lane_sums(const uint8_t *buf, int lane, int *s4, int *dc, int *s8)
+{
+    uint32_t r[4]; int t[16];
+    const int px = 4 * blk_x_of(lane & 15), py = 4 * blk_y_of(lane & 15);
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = lds4(buf + (py + k) * 16 + px);
+    had4x4_coefs(r, t);
+    int a4 = 0, a8 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { a4 += iabs(t[k]); a8 += iabs(quad_had2x2(t[k], lane & 3)); }
+    *s4 = a4; *dc = t[0]; *s8 = a8;
+}
+__device__ __forceinline__ void prim_fenc_complexity(const FrameDev &F, MBLocal *L)      /* x264_mb_cache_fenc_satd */
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    int satd = 0, sa8d = 0;
+    if (F.psy_rd) {
+        int s4, dc, s8;
+        had_lane_sums(L->fenc, lane, &s4, &dc, &s8);
+        int q8 = s8 + dpp_qp1(s8); q8 += dpp_qp2(q8);
+        int qd = dc + dpp_qp1(dc); qd += dpp_qp2(qd);
+        int a = lane < 16 ? (s4 >> 1) - (dc >> 1) : 0;
+        int b = (lane < 16 && (lane & 3) == 0) ? ((q8 + 2) >> 2) - (qd >> 2) : 0;
+        a = group_sum(a, 16); b = group_sum(b, 16);
+        satd = __builtin_amdgcn_readlane(a, 0); sa8d = __builtin_amdgcn_readlane(b, 0);
+    }
+    if (lane == 0) { L->fenc_satd_sum = satd; L->fenc_sa8d_sum = sa8d; }
+    PCAMV_WAVE_SYNC();
+}
+/* ssd_mb (rdo.c:106-137) of the reconstruction in L->pred: SSD of luma + both chroma planes, plus for luma the psy term
+ * |AC energy (4x4) difference| + |AC energy (8x8) difference| (the hadamard_ac branch: PIXEL_16x16 <= PIXEL_8x8) */
+__device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    int v = 0;
+    if (lane < 24) {
+        const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+        const int px = lane < 16 ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4, py = lane < 16 ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t e = lds4(L->fenc + (py + k) * 16 + px), p = lds4(L->pred + (py + k) * 16 + px);
+#pragma unroll
+            for (int x = 0; x < 4; x++) { const int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += dd * dd; }
+        }
+    }
+    int ssd = wave_sum_all(v);
+    if (F.psy_rd) {
+        int s4, dc, s8;
+        had_lane_sums(L->pred, lane, &s4, &dc, &s8);
+        if (lane >= 16) { s4 = 0; dc = 0; s8 = 0; }
+        s4 = group_sum(s4, 16); dc = group_sum(dc, 16); s8 = group_sum(s8, 16);
+        const int sum4 = (__builtin_amdgcn_readlane(s4, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 1;
+        const int sum8 = (__builtin_amdgcn_readlane(s8, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 2;
+        const int satd = (iabs(sum4 - L->fenc_satd_sum) + iabs(sum8 - L->fenc_sa8d_sum)) >> 1;
+        ssd += (satd * F.psy_rd * F.lambda + 128) >> 8;
+    }
+    PCAMV_WAVE_SYNC();
+    return ssd;
+}
+
+/* ---------------------------------------------------------------- CABAC size / context walk of the residual */
+__device__ __forceinline__ void prim_cabac_trial_begin(MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    if (lane < 22) ((uint32_t *)L_CAB(L, 1))[lane] = ((const uint32_t *)L_CAB(L, 0))[lane];      /* contexts 0..87: the macroblock header's */
+    PCAMV_WAVE_SYNC();
+}
+/* Bits (8.8) of coded_block_flag + significance map + levels of every coded block, in coding order (luma 4x4 blocks of the
+ * coded 8x8s, chroma DC, chroma AC).  The contexts of a category are held in lane registers while its blocks are walked:
+ * lane i owns significant_coeff_flag[i] and last_significant_coeff_flag[i], lane k < 10 owns coeff_abs_level_minus1 context
+ * k, lane k < 4 owns coded_block_flag increment k.  commit: write the adapted states back (the macroblock as coded);
+ * otherwise this is a size trial and the states are only read. */
+__device__ __forceinline__ int prim_cabac_residual(const FrameDev &F, MBLocal *L, int commit_)
+{
+    const int commit = rfl(commit_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    const int cbp_luma = rfl(L->cbp_luma), cbp_chroma = rfl(L->cbp_chroma);
+    int bits = 0;
+    uint8_t *S = L_CAB(L, 0);
+    const uint32_t *T = L_CTAB(L);
+    if (cbp_luma | cbp_chroma)
+        for (int pass = 0; pass < 3; pass++) {
+            if (pass == 1 && !(cbp_chroma & 3)) continue;
+            if (pass == 2 && !(cbp_chroma & 2)) continue;
+            if (pass == 0 && !cbp_luma) continue;
+            const int cat = 2 + pass, first = pass == 0 ? 0 : pass == 1 ? 25 : 16, nb = pass == 0 ? 16 : pass == 1 ? 2 : 8, count = pass == 0 ? 16 : pass == 1 ? 4 : 15;
+            const int sig_off = pass == 0 ? 134 : pass == 1 ? 149 : 152, last_off = pass == 0 ? 195 : pass == 1 ? 210 : 213, lvl_off = pass == 0 ? 247 : pass == 1 ? 257 : 266;
+            int sigS = lane < count - 1 ? S[sig_off + lane] : 0, lastS = lane < count - 1 ? S[last_off + lane] : 0;
+            int lvlS = lane < 10 ? S[lvl_off + lane] : 0, cbfS = lane < 4 ? S[85 + 4 * cat + lane] : 0;
+            for (int k = 0; k < nb; k++) {
+                const int idx = first + k;
+                if (pass == 0 && !(cbp_luma & (1 << (k >> 2)))) continue;
+                int inc;
+                if (pass == 1) {
+                    const int cl = L->cbp_left, ct = L->cbp_top;
+                    inc = (cl != -1 ? (cl >> (9 + k)) & 1 : 0) + 2 * (ct != -1 ? (ct >> (9 + k)) & 1 : 0);
+                } else {
+                    const int p8 = scan8_all_of(idx);
+                    inc = ((L->nzc[p8 - 1] & 0x7f) != 0) + 2 * ((L->nzc[p8 - 8] & 0x7f) != 0);
+                }
+                inc = rfl(inc);
+                const int flag = rfl(L->nzc[scan8_all_of(idx)] != 0);
+                if (lane == inc) { const uint32_t w = T[2 * cbfS + flag]; bits += (int)(w >> 8); cbfS = (int)(w & 255u); }
+                if (!flag) continue;
+                int lv = 0;
+                if (lane < count) lv = pass == 1 ? L->cdc[k][lane] : pass == 2 ? L->coef[idx][lane + 1] : L->coef[idx][lane];
+                const unsigned nzm = (unsigned)__ballot(lv != 0), gt1m = (unsigned)__ballot(iabs(lv) > 1);
+                if (!nzm) continue;                       /* cannot happen for a block flagged non-zero */
+                const int last = 31 - __builtin_clz(nzm);
+                if (lane < imin(last + 1, count - 1)) {
+                    uint32_t w = T[2 * sigS + (lv != 0)]; bits += (int)(w >> 8); sigS = (int)(w & 255u);
+                    if (lv != 0) { w = T[2 * lastS + (lane == last)]; bits += (int)(w >> 8); lastS = (int)(w & 255u); }
+                }
+                /* levels, from the last non-zero one down: node = min(#(|l| = 1) so far, 3) until a level above 1 was seen, then min(3 + #(|l| > 1), 7) */
+                int neq1 = 0, ngt1 = 0;
+                const int alv = iabs(lv);
+                for (unsigned m = nzm; m;) {
+                    const int i = 31 - __builtin_clz(m);
+                    m &= ~(1u << i);
+                    const int node = ngt1 ? imin(3 + ngt1, 7) : imin(neq1, 3);
+                    const int c1 = node < 4 ? node + 1 : 0, c2 = node < 4 ? 5 : imin(node + 2, 9);
+                    if ((gt1m >> i) & 1u) {
+                        const int am1 = __builtin_amdgcn_readlane(alv, i) - 1, prefix = imin(am1, 14);
+                        if (lane == c1) { const uint32_t w = T[2 * lvlS + 1]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
+                        if (lane == c2) {
+                            for (int q = 0; q < prefix - 1; q++) { const uint32_t w = T[2 * lvlS + 1]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
+                            if (prefix < 14) { const uint32_t w = T[2 * lvlS]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
+                        }
+                        if (prefix >= 14 && lane == 0) bits += size_ue_of((unsigned)(am1 - 14)) << 8;
+                        ngt1++;
+                    } else {
+                        if (lane == c1) { const uint32_t w = T[2 * lvlS]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
+                        neq1++;
+                    }
+                    if (lane == 0) bits += 256;       /* sign */
+                }
+            }
+            if (commit) {
+                if (lane < count - 1) { S[sig_off + lane] = (uint8_t)sigS; S[last_off + lane] = (uint8_t)lastS; }
+                if (lane < 10) S[lvl_off + lane] = (uint8_t)lvlS;
+                if (lane < 4) S[85 + 4 * cat + lane] = (uint8_t)cbfS;
+            }
+        }
+    const int total = wave_sum_all(bits);
+    (void)F;
+    PCAMV_WAVE_SYNC();
+    return total;
+}
+
+/* ---------------------------------------------------------------- CAVLC size of the macroblock layer */
+__device__ static const uint8_t vlc_coeff0_len_dev[5] = {1, 2, 4, 6, 2};
+#include "pcamv_vlc_dev.h"
+__device__ __forceinline__ int cavlc_level_size(int level, int *suffix_len)      /* common/vlc.c:874-914, cavlc.c:63-107 */
+{
+    int sl = *suffix_len, a = iabs(level), code = a * 2 - 2 + (level < 0), size, next = sl;
+    if ((code >> sl) < 14) size = (code >> sl) + 1 + sl;
+    else if (sl == 0 && code < 30) size = 19;
+    else if (sl > 0 && (code >> sl) == 14) size = 15 + sl;
+    else { code -= 15 << sl; if (sl == 0) code -= 15; size = 28; if (code >= 1 << 12) size += 1000000; }
+    if (next == 0) next++;
+    if (a > (3 << (next - 1)) && next < 6) next++;
+    *suffix_len = next;
+    return size;
+}
+PCAMV_DEV int size_se_of(int v) { return size_ue_of((unsigned)(v <= 0 ? -v * 2 : v * 2 - 1)); }
+/* x264_macroblock_write_cavlc as a bit counter (encoder/cavlc.c:290-600; rdo.c:41-47): one residual block per lane (0..15 luma,
+ * 16..23 chroma AC, 24 / 25 chroma DC).  First every lane counts its coefficients (what the neighbours' nC reads, cavlc.c:133),
+ * then sizes its block with nC from the counts.  Leaves the counts in L->nzc. */
+__device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    const int cbp_luma = rfl(L->cbp_luma), cbp_chroma = rfl(L->cbp_chroma);
+    int bits = 0;
+    /* header: every lane the same walk, counted on lane 0 */
+    {
+        int hb = 0, mvp[2];
+#define GMVD(idx, w) (predict_mv(L, idx, w, mvp), size_se_of(L->cmv[scan8_of(idx)][0] - mvp[0]) + size_se_of(L->cmv[scan8_of(idx)][1] - mvp[1]))
+        if (L->i_type == PCAMV_P_8x8) {
+            hb += size_ue_of(3);
+            for (int i = 0; i < 4; i++) { const int sp = L->sub_part[i]; hb += size_ue_of(sp == PCAMV_D_L0_8x8 ? 0 : sp == PCAMV_D_L0_8x4 ? 1 : sp == PCAMV_D_L0_4x8 ? 2 : 3); }
+            for (int i = 0; i < 4; i++)
+                switch (L->sub_part[i]) {
+                case PCAMV_D_L0_8x8: hb += GMVD(4 * i, 2); break;
+                case PCAMV_D_L0_8x4: hb += GMVD(4 * i, 2); hb += GMVD(4 * i + 2, 2); break;
+                case PCAMV_D_L0_4x8: hb += GMVD(4 * i, 1); hb += GMVD(4 * i + 1, 1); break;
+                default: for (int k = 0; k < 4; k++) hb += GMVD(4 * i + k, 1); break;
+                }
+        } else if (L->i_partition == PCAMV_D_16x16) { hb += size_ue_of(0); hb += GMVD(0, 4); }
+        else if (L->i_partition == PCAMV_D_16x8) { hb += size_ue_of(1); hb += GMVD(0, 4); hb += GMVD(8, 4); }
+        else { hb += size_ue_of(2); hb += GMVD(0, 2); hb += GMVD(4, 2); }
+#undef GMVD
+        hb += size_ue_of(vlc_inter_cbp_golomb_dev[(cbp_chroma << 4) | cbp_luma]);
+        if (cbp_luma | cbp_chroma) hb += 1;          /* mb_qp_delta = 0 */
+        if (lane == 0) bits = hb;
+    }
+    /* which block this lane codes, and whether it is coded at all */
+    const int idx = lane < 24 ? lane : 25 + (lane - 24);
+    const bool mine = lane < 26 && (lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) : lane < 24 ? (cbp_chroma & 2) != 0 : cbp_chroma != 0);
+    const int count = lane < 16 ? 16 : lane < 24 ? 15 : 4;
+    const int p8 = scan8_all_of(lane < 26 ? idx : 0);
+    int level[16], total = 0, last = -1, trailing = 0;
+    const bool flag = mine && L->nzc[p8] != 0;
+    if (flag) {
+        const int16_t *l = lane < 16 ? L->coef[lane] : lane < 24 ? L->coef[lane] + 1 : L->cdc[lane - 24];
+#pragma unroll
+        for (int i = 15; i >= 0; i--) {
+            const int v = i < count ? l[i] : 0;
+            if (v) { if (last < 0) last = i; level[total & 15] = v; total++; }
+        }
+    }
+    PCAMV_WAVE_SYNC();
+    if (flag) L->nzc[p8] = (uint8_t)total;
+    PCAMV_WAVE_SYNC();
+    if (mine) {
+        int nC = 4;
+        if (lane < 24) { int r = L->nzc[p8 - 1] + L->nzc[p8 - 8]; if (r < 0x80) r = (r + 1) >> 1; r &= 0x7f; nC = r < 2 ? 0 : r < 4 ? 1 : r < 8 ? 2 : 3; }
+        if (!flag) bits += vlc_coeff0_len_dev[nC];
+        else {
+            const int16_t *l = lane < 16 ? L->coef[lane] : lane < 24 ? L->coef[lane] + 1 : L->cdc[lane - 24];
+            while (trailing < 3 && trailing < total && iabs(level[trailing]) == 1) trailing++;
+            bits += vlc_coeff_len_dev[nC * 64 + total * 4 + trailing - 4] + trailing;
+            int sl = total > 10 && trailing < 3;
+            if (trailing < total) {
+                int v = level[trailing], s1 = sl, s2 = sl;
+                if (trailing < 3) v -= v < 0 ? -1 : 1;
+                bits += cavlc_level_size(v, &s1);
+                cavlc_level_size(level[trailing], &s2); sl = s2;
+                for (int i = trailing + 1; i < total; i++) bits += cavlc_level_size(level[i], &sl);
+            }
+            int total_zero = last + 1 - total;
+            if (total < count) bits += lane >= 24 ? vlc_total_zeros_dc_len_dev[(total - 1) * 4 + total_zero] : vlc_total_zeros_len_dev[(total - 1) * 16 + total_zero];
+            /* run_before: zeros between consecutive levels, from the top */
+            int pos = last;
+            for (int i = 0; i < total - 1 && total_zero > 0; i++) {
+                int run = 0;
+                while (--pos >= 0 && !l[pos]) run++;
+                bits += vlc_run_before_len_dev[imin(total_zero - 1, 6) * 16 + run];
+                total_zero -= run;
+            }
+        }
+    }
+    const int sum = wave_sum_all(bits);
+    (void)F;
+    PCAMV_WAVE_SYNC();
+    return sum;
+}
+
+/* what the coded macroblock leaves for its neighbours and successors: bottom row / right column of the non-zero cache, coded
+ * block pattern, MV differences, the slice's context states -- stored write-through, like the motion the search hands over */
+__device__ __forceinline__ void prim_rd_commit(const FrameDev &F, MBLocal *L, int skip_)
+{
+    const int skip = rfl(skip_);
+    const int lane = LANE();
+    const int xy = L->mb_xy;
+    PCAMV_WAVE_SYNC();
+    if (lane < 16) {
+        const int k = lane & 7, is_right = lane >> 3;
+        const int blk = is_right ? (k < 4 ? (k == 0 ? 5 : k == 1 ? 7 : k == 2 ? 13 : 15) : 17 + 2 * (k - 4)) : (k < 4 ? (k == 0 ? 10 : k == 1 ? 11 : k == 2 ? 14 : 15) : k < 6 ? 18 + (k - 4) : 22 + (k - 6));
+        NB_ST8(&F.nb_nz[xy * 16 + lane], skip ? 0 : L->nzc[scan8_all_of(blk)]);
+    } else if (lane < 24) {
+        const int k = lane - 16, pos = k < 4 ? SCAN8_0 + k + 8 * 3 : SCAN8_0 + 3 + 8 * (k - 4);
+        NB_ST32(&F.nb_mvd[(xy * 8 + k) * 2], skip ? 0u : ((const uint32_t *)L->cmvd)[pos]);
+    } else if (lane == 24) {
+        const int cbp = skip ? 0 : ((F.b_cabac ? (L->nzc[scan8_all_of(25)] << 9 | L->nzc[scan8_all_of(26)] << 10) : 0) | L->cbp_chroma << 4 | L->cbp_luma);
+        NB_ST16(&F.nb_cbp[xy], cbp);
+    }
+    if (F.b_cabac) {
+        const uint32_t *src = (const uint32_t *)L_CAB(L, 0);
+        NB_ST32((uint32_t *)F.cabac + lane, src[lane]);
+        if (lane < 52) NB_ST32((uint32_t *)F.cabac + 64 + lane, src[64 + lane]);
+        if (F.dbg_hash && lane == 0) {
+            uint32_t h = 2166136261u;
+            for (int i = 0; i < 460; i++) h = (h ^ L_CAB(L, 0)[i]) * 16777619u;
+            F.dbg_hash[xy] = h;
+        }
+    }
+    PCAMV_WAVE_SYNC();
+}
+#endif

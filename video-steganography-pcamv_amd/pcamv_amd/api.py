@@ -9,7 +9,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 
 ME_NAMES = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}      # x264_motion_est_names, x264.h:113
 P_L0, P_8x8, P_SKIP = 4, 5, 6
-PSUB16x16, PSUB8x8 = 0x10, 0x20
+I4x4, PSUB16x16, PSUB8x8 = 0x01, 0x10, 0x20
 
 
 class PcamvError(RuntimeError):
@@ -22,7 +22,7 @@ class Params(C.Structure):
                 ("i_me_range", C.c_int32), ("i_subpel_refine", C.c_int32), ("i_mv_range", C.c_int32),
                 ("b_chroma_me", C.c_int32), ("b_fast_pskip", C.c_int32), ("b_dct_decimate", C.c_int32),
                 ("b_cabac", C.c_int32), ("inter", C.c_uint32), ("i_chroma_qp_offset", C.c_int32),
-                ("i_luma_deadzone", C.c_int32 * 2), ("i_tscale", C.c_int32)]
+                ("i_luma_deadzone", C.c_int32 * 2), ("i_tscale", C.c_int32), ("i_psy_rd", C.c_int32)]
 
 
 class _Embed(C.Structure):
@@ -54,18 +54,29 @@ def level_mv_range(width, height, fps=25):
     return 512
 
 
+def _validate(p):
+    """the part of x264_validate_parameters that couples these fields (encoder.c:511-522): psy-RD acts from subme 6 on and
+    lowers the chroma QP offset by 2 (by 1 below strength 0.25); the user's own values are kept on the side"""
+    f = p._f_psy_rd if p.i_subpel_refine >= 6 else 0.0
+    p.i_psy_rd = int(min(max(f, 0.0), 10.0) * 256 + 0.5)
+    off = p._chroma_qp_offset - ((1 if f < 0.25 else 2) if p.i_psy_rd else 0)
+    p.i_chroma_qp_offset = min(max(off, -12), 12)
+    return p
+
+
 def param_default(width, height):
-    """x264_param_default (common/common.c:39-146) for the fields of this path."""
+    """x264_param_default (common/common.c:39-146) for the fields of this path, then what x264_validate_parameters makes
+    of them: subme 6 (RD mode decision), me hex, partitions p8x8 + i4x4, CABAC, psy-rd 1.0."""
     p = Params()
     p.i_width, p.i_height = width, height
-    p.i_me_method, p.i_me_range, p.i_subpel_refine = ME_NAMES["hex"], 16, 5
+    p.i_me_method, p.i_me_range, p.i_subpel_refine = ME_NAMES["hex"], 16, 6
     p.i_mv_range = level_mv_range(width, height)
     p.b_chroma_me = p.b_fast_pskip = p.b_dct_decimate = p.b_cabac = 1
-    p.inter = PSUB16x16
-    p.i_chroma_qp_offset = 0
+    p.inter = I4x4 | PSUB16x16
     p.i_luma_deadzone[0], p.i_luma_deadzone[1] = 21, 11
     p.i_tscale = 256
-    return p
+    p._f_psy_rd, p._chroma_qp_offset = 1.0, 0
+    return _validate(p)
 
 
 def param_parse(p, name, value):
@@ -86,6 +97,8 @@ def param_parse(p, name, value):
         toks = [t.strip() for t in str(value).split(",")]
         if "none" in toks:
             v = 0
+        if "all" in toks or "i4x4" in toks:
+            v |= I4x4
         if "all" in toks or "p8x8" in toks:
             v |= PSUB16x16
         if "all" in toks or "p4x4" in toks:
@@ -102,10 +115,12 @@ def param_parse(p, name, value):
     elif name == "no-cabac":
         p.b_cabac = 0
     elif name == "chroma-qp-offset":
-        p.i_chroma_qp_offset = int(value)
+        p._chroma_qp_offset = int(value)
+    elif name == "psy-rd":
+        p._f_psy_rd = float(str(value).split(":")[0])
     else:
         raise PcamvError(f"unknown option: {name}")
-    return p
+    return _validate(p)
 
 
 def lib_path():
@@ -114,8 +129,8 @@ def lib_path():
 
 
 def build_library(force=False):
-    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa kernels, compiled side
-    by side) into the in-tree libpcamv_gpu.so."""
+    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa instance, and csrc/pcamv_rd.hip,
+    the --subme 6 / 7 instance, compiled side by side) into the in-tree libpcamv_gpu.so."""
     out = lib_path()
     srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if not f.endswith(".o")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "pcamv_gpu.h"))
@@ -123,7 +138,7 @@ def build_library(force=False):
         return out
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
     objs, procs = [], []
-    for unit in ("pcamv_gpu", "pcamv_tesa"):
+    for unit in ("pcamv_gpu", "pcamv_tesa", "pcamv_rd"):
         obj = os.path.join(_CSRC, unit + ".o")
         objs.append(obj)
         procs.append(subprocess.Popen(["hipcc", *flags, "-c", "-o", obj, os.path.join(_CSRC, unit + ".hip")]))
@@ -178,7 +193,7 @@ class Encoder:
         rc = self.lib.pcamv_gpu_open(C.byref(params), device, C.byref(ctx))
         if rc:
             names = {-1: "invalid parameter", -2: "no HIP device (there is no CPU fallback)", -3: "out of memory",
-                     -4: "HIP error", -5: "unsupported (subme >= 6, tesa with me_range > 16, picture not a multiple of 16, ... are not on the GPU path)"}
+                     -4: "HIP error", -5: "unsupported (subme >= 8, subme >= 6 with p4x4 partitions or --me tesa, tesa with me_range > 16, ... are not on the GPU path)"}
             raise PcamvError(f"pcamv_gpu_open failed: {names.get(rc, rc)}")
         self.ctx = ctx
 
@@ -269,6 +284,15 @@ class Encoder:
             flips = np.ascontiguousarray(flips, np.uint8)
         self._chk(self.lib.pcamv_gpu_pass2_pframe(self.ctx, _p(flips), 0 if flips is None else len(flips), _p(out), rec, dbk), "pass2_pframe")
         return out, tuple(planes[:3]), tuple(planes[3:])
+
+    def debug_state_hash(self, enable=True):
+        """diagnostics: FNV-1a of the CABAC context states after every macroblock of the following analyses (--subme >= 6)"""
+        self._chk(self.lib.pcamv_gpu_debug_state_hash(self.ctx, int(enable)), "debug_state_hash")
+
+    def state_hash_fetch(self):
+        out = np.zeros(self.n_mb, np.uint32)
+        self._chk(self.lib.pcamv_gpu_debug_state_hash_fetch(self.ctx, _p(out)), "debug_state_hash_fetch")
+        return out
 
     def block_costs(self, qp, requests):
         req = np.ascontiguousarray(requests, np.int32).reshape(-1, 8)

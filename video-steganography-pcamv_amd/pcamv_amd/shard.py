@@ -1,10 +1,14 @@
 """Closed-GOP sharding across the GPUs of one node (parity definition P1).
 
 Every closed GOP is an independent unit (IDR resets the reference list; CQP removes the
-rate-control coupling), so rank r of `world` simply owns GOPs r, r+world, ...; there is no
-data-path collective.  What is exchanged is the per-GOP result (the record summary here, the NAL
-bytes in a full encoder), gathered to rank 0 over torch.distributed (RCCL on the GPU box, gloo in
-the CPU tests)."""
+rate-control coupling), so rank r of `world` owns GOPs r, r+world, ...; there is no data-path
+collective.  What is exchanged is the per-GOP result: a byte payload per GOP (the pass-1 records +
+flip maps here -- the stand-in for the NAL bytes until an entropy coder exists on this side of the
+boundary), gathered to rank 0 with tensor collectives only (sizes: all_gather of int64; bytes:
+gather of padded uint8), so it runs on RCCL over xGMI without pickling through the host, and on
+gloo in the CPU tests.
+"""
+import numpy as np
 
 
 def gop_assignment(n_gops, world, rank):
@@ -14,18 +18,47 @@ def gop_assignment(n_gops, world, rank):
     return list(range(rank, n_gops, world))
 
 
-def gather_results(dist, local_results, n_gops, world, rank):
-    """Gather {gop_index: payload} dicts to rank 0 and return them in GOP order (None elsewhere)."""
+def pack_gop_payload(mbs, flip):
+    """bytes of one GOP-frame result: the records (pcamv_mb_t array) followed by the flip map"""
+    return np.ascontiguousarray(mbs).view(np.uint8).tobytes() + np.ascontiguousarray(flip, dtype=np.int8).tobytes()
+
+
+def gather_payloads(dist, local, n_gops, world, rank, device=None):
+    """local: {gop_index: bytes} of the GOPs this rank owns.  Returns the n_gops payloads in GOP order on rank 0
+    (None elsewhere).  Collectives: one all_gather of the per-GOP sizes, one gather of the padded byte buffers."""
+    import torch
+    mine = gop_assignment(n_gops, world, rank)
+    if sorted(local) != mine:
+        raise ValueError(f"rank {rank} owns GOPs {mine}, got {sorted(local)}")
     if dist is None or world == 1:
-        return [local_results[g] for g in range(n_gops)]
-    bucket = [None] * world if rank == 0 else None
-    dist.gather_object(local_results, bucket, dst=0)
+        return [local[g] for g in range(n_gops)]
+    dev = device if device is not None else torch.device("cpu")
+    per_rank = (n_gops + world - 1) // world
+    sizes = torch.zeros(per_rank, dtype=torch.int64, device=dev)
+    for k, g in enumerate(mine):
+        sizes[k] = len(local[g])
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    cap = int(max(int(s.sum()) for s in all_sizes))
+    buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    off = 0
+    for g in mine:
+        b = torch.frombuffer(bytearray(local[g]), dtype=torch.uint8)
+        buf[off:off + len(b)] = b.to(dev)
+        off += len(b)
+    bucket = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, bucket, dst=0)
     if rank != 0:
         return None
-    merged = {}
-    for part in bucket:
-        merged.update(part)
-    missing = [g for g in range(n_gops) if g not in merged]
+    out = [None] * n_gops
+    for r in range(world):
+        data = bucket[r].cpu().numpy().tobytes()
+        off = 0
+        for k, g in enumerate(gop_assignment(n_gops, world, r)):
+            n = int(all_sizes[r][k])
+            out[g] = data[off:off + n]
+            off += n
+    missing = [g for g in range(n_gops) if out[g] is None]
     if missing:
         raise RuntimeError(f"GOPs {missing} were not produced by any rank")
-    return [merged[g] for g in range(n_gops)]
+    return out
