@@ -120,7 +120,7 @@ def main():
     prof = None
     if os.environ.get("PCAMV_PROF_DUMP") == "1":      # diagnostics build of the library (-DPCAMV_PROF): wave cycles per phase
         import ctypes
-        prof = (ctypes.c_ulonglong * 24)()
+        prof = (ctypes.c_ulonglong * 32)()
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 1)
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -171,7 +171,9 @@ def main():
                  "final qpel refine", "reconstruction", "neighbour load", "record store",
                  "pop: ticket (or pass 2: pop+wait)", "pop: queue entry wait (or pass 2: work)", "pop: descriptor load (or pass 2: publish)",
                  "rd: intra SATD analysis", "rd: x264_mb_analyse_p_rd", "rd trial: predict + transform", "rd trial: ssd + psy", "rd trial: cabac header",
-                 "rd trial: cabac residual", "rd: final encode + entropy commit", "-"]
+                 "rd trial: cabac residual", "rd: final encode + entropy commit", "-",
+                 "residual: per-block data", "residual: coded_block_flag chains", "residual: maps + levels", "COUNT residual walks", "COUNT blocks with levels",
+                 "COUNT coded blocks", "COUNT non-zero levels", "-"]
         print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
     # dominant kernel: average duration of one launch, HIP events on its own stream
     dom = batch.dominant_kernel()

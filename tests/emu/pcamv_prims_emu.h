@@ -10,8 +10,6 @@
 #include "pcamv_common.h"
 #include "pcamv_entropy_tables.h"
 
-static inline void cb_dec(MBLocal *L, uint8_t *S, int ctx, int b, int *bits);
-static inline int size_ue_of(unsigned v);
 static inline void predict_mv(MBLocal *L, int idx, int width, int mvp[2]);
 /* the reference's own tables (common/mc.c:194-200 hpel_ref0/1, dct.h zigzag, quant.c:203 decimate table) for the scalar restatement */
 static const int hpel_ref0_tab[16] = {0, 1, 1, 1, 0, 1, 1, 1, 2, 3, 3, 3, 0, 1, 1, 1};
@@ -595,19 +593,23 @@ static inline int prim_ssd_mb(const FrameDev &F, MBLocal *L)                /* s
     }
     return ssd;
 }
-static inline void prim_cabac_trial_begin(MBLocal *L) { memcpy(L_CAB(L, 1), L_CAB(L, 0), 88); }
-/* residual_block_cabac for every coded block of the macroblock (encoder/cabac.c:582-667, 1000-1018): the header contexts of a
- * trial are the copy, the residual contexts are read from the slice states and only written back when committing */
-static inline int prim_cabac_residual(const FrameDev &F, MBLocal *L, int commit)
+/* the CABAC walk of one macroblock: a trial walks a copy of the slice's states, the committing walk the states themselves */
+struct CabWalk { uint8_t tmp[464]; uint8_t *S; int bits; };
+static inline void prim_cab_begin(MBLocal *L, CabWalk &C) { memcpy(C.tmp, L_CAB(L, 0), 464); C.S = C.tmp; C.bits = 0; }
+static inline void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx, int b)
+{
+    const uint32_t w = L_CTAB(L)[2 * C.S[ctx] + b];
+    C.S[ctx] = (uint8_t)(w & 255u); C.bits += (int)(w >> 8);
+}
+static inline void prim_cb_bypass(CabWalk &C, int f8) { C.bits += f8; }
+static inline int prim_cab_end(MBLocal *L, CabWalk &C, int commit) { if (commit) memcpy(L_CAB(L, 0), C.S, 464); return C.bits; }
+/* residual_block_cabac for every coded block of the macroblock (encoder/cabac.c:582-667, 1000-1018) */
+static inline void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit)
 {
     static const uint16_t sig_off[5] = {105, 120, 134, 149, 152}, last_off[5] = {166, 181, 195, 210, 213}, lvl_off[5] = {227, 237, 247, 257, 266};
     static const uint8_t lvl1[8] = {1, 2, 3, 4, 0, 0, 0, 0}, lvlgt1[8] = {5, 5, 5, 5, 6, 7, 8, 9}, nxt[2][8] = {{1, 2, 3, 3, 4, 5, 6, 7}, {4, 4, 4, 4, 5, 6, 7, 7}};
-    uint8_t tmp[464];
-    uint8_t *S = L_CAB(L, 0);
-    if (!commit) { memcpy(tmp, S, 464); S = tmp; }
-    int bits = 0;
-    (void)F;
-    if (!(L->cbp_luma | L->cbp_chroma)) return 0;
+    (void)F; (void)commit;
+    if (!(L->cbp_luma | L->cbp_chroma)) return;
     for (int pass = 0; pass < 3; pass++) {
         const int cat = 2 + pass, first = pass == 0 ? 0 : pass == 1 ? 25 : 16, nb = pass == 0 ? 16 : pass == 1 ? 2 : 8, count = pass == 0 ? 16 : pass == 1 ? 4 : 15;
         if (pass == 1 && !(L->cbp_chroma & 3)) continue;
@@ -625,29 +627,28 @@ static inline int prim_cabac_residual(const FrameDev &F, MBLocal *L, int commit)
             }
             const int16_t *l = pass == 1 ? L->cdc[k] : pass == 2 ? L->coef[idx] + 1 : L->coef[idx];
             const int flag = L->nzc[scan8_all_of(idx)] != 0;
-            cb_dec(L, S, 85 + inc, flag, &bits);
+            prim_cb_dec(L, C, 85 + inc, flag);
             if (!flag) continue;
             int last = count - 1;
             while (last >= 0 && !l[last]) last--;
             for (int i = 0; i < imin(last + 1, count - 1); i++) {
-                cb_dec(L, S, sig_off[cat] + i, l[i] != 0, &bits);
-                if (l[i]) cb_dec(L, S, last_off[cat] + i, i == last, &bits);
+                prim_cb_dec(L, C, sig_off[cat] + i, l[i] != 0);
+                if (l[i]) prim_cb_dec(L, C, last_off[cat] + i, i == last);
             }
             int node = 0;
             for (int i = last; i >= 0; i--) {
                 if (!l[i]) continue;
                 const int am1 = iabs(l[i]) - 1, prefix = imin(am1, 14);
                 if (prefix) {
-                    cb_dec(L, S, lvl_off[cat] + lvl1[node], 1, &bits);
-                    for (int q = 0; q < prefix - 1; q++) cb_dec(L, S, lvl_off[cat] + lvlgt1[node], 1, &bits);
-                    if (prefix < 14) cb_dec(L, S, lvl_off[cat] + lvlgt1[node], 0, &bits); else bits += size_ue_of((unsigned)(am1 - 14)) << 8;
+                    prim_cb_dec(L, C, lvl_off[cat] + lvl1[node], 1);
+                    for (int q = 0; q < prefix - 1; q++) prim_cb_dec(L, C, lvl_off[cat] + lvlgt1[node], 1);
+                    if (prefix < 14) prim_cb_dec(L, C, lvl_off[cat] + lvlgt1[node], 0); else C.bits += size_ue_of((unsigned)(am1 - 14)) << 8;
                     node = nxt[1][node];
-                } else { cb_dec(L, S, lvl_off[cat] + lvl1[node], 0, &bits); node = nxt[0][node]; }
-                bits += 256;
+                } else { prim_cb_dec(L, C, lvl_off[cat] + lvl1[node], 0); node = nxt[0][node]; }
+                C.bits += 256;
             }
         }
     }
-    return bits;
 }
 static inline int emu_cavlc_level(int level, int *suffix_len)
 {

@@ -19,7 +19,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pcamv_gpu.h but not exported"
-    assert lib.pcamv_gpu_abi_version() == 1
+    assert lib.pcamv_gpu_abi_version() == 2     # round 2: i_psy_rd appended to pcamv_params_t, the debug state-hash entry points
 
 
 def test_no_cpu_fallback_without_a_device():
@@ -44,7 +44,10 @@ def test_product_does_not_reference_the_oracle():
 def test_param_parse_mirrors_reference_option_names():
     import pcamv_amd
     p = pcamv_amd.param_default(1920, 1088)
-    assert (p.i_me_method, p.i_me_range, p.i_subpel_refine, p.inter, p.i_mv_range) == (1, 16, 5, 0x10, 512)
+    # x264_param_default (common/common.c:83-140) as main() leaves it: hex, range 16, subme 6, i4x4 + p8x8, psy-rd 1.0 -> 256 and
+    # the chroma QP offset it implies at subme >= 6 (encoder.c:513-521)
+    assert (p.i_me_method, p.i_me_range, p.i_subpel_refine, p.inter, p.i_mv_range) == (1, 16, 6, 0x11, 512)
+    assert (p.i_psy_rd, p.i_chroma_qp_offset, p.b_cabac) == (256, -2, 1)
     pcamv_amd.param_parse(p, "--me", "umh"); pcamv_amd.param_parse(p, "subme", 4); pcamv_amd.param_parse(p, "partitions", "p8x8,p4x4")
     assert (p.i_me_method, p.i_subpel_refine, p.inter) == (2, 4, 0x30)
     with pytest.raises(pcamv_amd.PcamvError):

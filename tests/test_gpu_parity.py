@@ -240,6 +240,15 @@ def test_embedding_edge_cases(pc):
             assert np.array_equal(a[k], b[k]), (bits, k)
     a, b = enc.embed_pframe(float(n + 5)), o.embed_pframe(mbs_o, float(n + 5))
     assert a["stc_ok"] == 0 and b["stc_ok"] == 0 and np.array_equal(a["flip"], a["cover"].astype(np.int8)) and np.array_equal(a["flip"], b["flip"])
+    # a bits-per-frame rate beyond the arrays' capacity (16 per macroblock): fails like any m > n, writes nothing out of bounds,
+    # and the rand() stream has advanced by m all the same (the next frame's message continues from there)
+    cap = 16 * len(mbs)
+    a = enc.embed_pframe(float(cap + 2000))
+    assert a["stc_ok"] == 0 and a["m"] == cap + 2000 and len(a["message"]) == cap and np.array_equal(a["flip"], a["cover"].astype(np.int8))
+    nxt = enc.embed_pframe(40.5)
+    consumed = sum(bits for bits in (2, 3, 5, 7, 9, 10, 11)) + (n + 5)        # rand() calls before the oversized request (the first embedding had a caller's message)
+    stream = np.array([v & 1 for v in orc.glibc_rand(consumed + cap + 2000 + 40)], np.uint8)
+    assert np.array_equal(nxt["message"], stream[consumed + cap + 2000:])
     # identical frames, no noise: every MB becomes P_SKIP, no carriers
     enc.set_ref(*clip[0]); enc.upload_fenc(*clip[0])
     mbs, _ = enc.analyse_pframe(30, 1)

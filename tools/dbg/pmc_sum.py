@@ -1,6 +1,6 @@
 import csv, glob, collections, sys
 tag = sys.argv[1]; mbs = float(sys.argv[2]) if len(sys.argv) > 2 else 0
-for d in ('a', 'b'):
+for d in ('a', 'b', 'c'):
     for f in glob.glob(f'gpurun_out/pmc_{tag}_{d}/*/*counter_collection.csv'):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):

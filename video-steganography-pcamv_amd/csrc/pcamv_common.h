@@ -254,10 +254,12 @@ struct MEState {
 
 /* diagnostics build (-DPCAMV_PROF): wave cycles per phase of k_analyse_flow, summed in pcamv_prof[] (tools/dbg/prof_phases.py) */
 #if defined(PCAMV_PROF) && !defined(PCAMV_HOST_EMU)
-static __device__ unsigned long long pcamv_prof[24];
+static __device__ unsigned long long pcamv_prof[32];
 #define PROF_T() __builtin_readcyclecounter()
 #define PROF_ADD(i, t0) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(PROF_T() - (t0))); } while (0)
+#define PROF_CNT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(n)); } while (0)
 #else
+#define PROF_CNT(i, n) do { } while (0)
 #define PROF_T() 0ull
 #define PROF_ADD(i, t0) do { (void)(t0); } while (0)
 #endif

@@ -50,7 +50,8 @@ struct pcamv_ctx {
     uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_chroma[2], *d_rec[3];
     int8_t *d_mb_type, *d_ref8, *d_prev_ref, *d_ref8_b;
     int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux, *d_mv_b;
-    int pp, prev_internal;      /* ping-pong of the motion field for device-resident chains */
+    int last_field, prev_internal;   /* ping-pong of the motion field for device-resident chains: which of d_mv (0) / d_mv_b (1) the last analysis wrote */
+    pcamv_batch *member_of[16]; int n_member;    /* batches this context belongs to (its own included): told when it closes */
     pcamv_mb_t *d_rec_mb;
     int16_t *d_cost_mv[52];
     uint8_t *d_cover, *d_stego, *d_message, *d_user_msg; unsigned *d_colinfo;
@@ -81,11 +82,11 @@ extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
-    unsigned long long rd[24];
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    unsigned long long rd[32];
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
     if (pcamv_rd_prof_fetch(rd, reset)) return -1;
-    for (int i = 0; i < 24; i++) out[i] += rd[i];
+    for (int i = 0; i < 32; i++) out[i] += rd[i];
     return 0;
 }
 #endif
@@ -120,7 +121,12 @@ extern "C" void pcamv_gpu_batch_destroy(pcamv_batch_t *b)
     if (!b) return;
     hipSetDevice(b->device);
     hipDeviceSynchronize();
-    for (int i = 0; b->ctx && i < b->n; i++) if (b->ctx[i]->last == b) b->ctx[i]->last = NULL;   /* destroy a batch before its contexts */
+    for (int i = 0; b->ctx && i < b->n; i++) {          /* contexts closed before the batch have taken themselves out (NULL) */
+        pcamv_ctx *c = b->ctx[i];
+        if (!c) continue;
+        if (c->last == b) c->last = NULL;
+        for (int k = 0; k < c->n_member; k++) if (c->member_of[k] == b) { c->member_of[k] = c->member_of[--c->n_member]; break; }
+    }
     if (b->h_F) hipHostFree(b->h_F);
     if (b->h_E) hipHostFree(b->h_E);
     hipFree(b->d_F); hipFree(b->d_E);
@@ -200,6 +206,8 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         if (e == hipSuccess) e = hipMemset(b->d_flow, 0, FLOW_CTR_WORDS * sizeof(unsigned));
     }
     if (e != hipSuccess) { pcamv_gpu_batch_destroy(b); return PCAMV_EHIP; }
+    for (int i = 0; i < n; i++) if (ctxs[i]->n_member >= 16) { pcamv_gpu_batch_destroy(b); return PCAMV_EINVAL; }
+    for (int i = 0; i < n; i++) ctxs[i]->member_of[ctxs[i]->n_member++] = b;
     for (int i = 0; i < n; i++)         /* the kernel instance with --me tesa compiled in exists for the dataflow schedule only */
         if ((ctxs[i]->F.me_method == PCAMV_ME_TESA || ctxs[i]->F.b_mbrd) && !b->sched_flow) { pcamv_gpu_batch_destroy(b); return PCAMV_EUNSUP; }     /* ... and so does the RD mode decision */
     *out = b;
@@ -230,6 +238,7 @@ extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) {
 /* ------------------------------------------------------------------ contexts */
 extern "C" void pcamv_gpu_close(pcamv_ctx_t *c);
 
+static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device);
 extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t **out)
 {
     if (!p || !out) return PCAMV_EINVAL;
@@ -247,7 +256,14 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     pcamv_ctx *c = new (std::nothrow) pcamv_ctx();
     if (!c) return PCAMV_ENOMEM;
     memset((void *)c, 0, sizeof(*c));
-    c->p = *p; c->device = device;
+    c->p = *p; c->device = device; c->last_field = 1;
+    const int rc = open_impl(c, p, device);
+    if (rc) { pcamv_gpu_close(c); return rc; }          /* one cleanup path: whatever was allocated so far is released */
+    *out = c;
+    return 0;
+}
+static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
+{
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     FrameDev &F = c->F;
@@ -304,10 +320,7 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     E.flip = c->d_flip; E.hdr = c->d_hdr; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
     E.lcg = c->d_lcg; E.colinfo = c->d_colinfo; E.cap = c->cap; E.car_base = c->d_car_base; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
     pcamv_ctx *one[1] = {c};
-    int rc = pcamv_gpu_batch_create(one, 1, &c->self);
-    if (rc) { pcamv_gpu_close(c); return rc; }
-    *out = c;
-    return 0;
+    return pcamv_gpu_batch_create(one, 1, &c->self);
 }
 
 extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
@@ -316,6 +329,10 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->self) pcamv_gpu_batch_destroy(c->self);
+    for (int k = 0; k < c->n_member; k++) {             /* batches that outlive this context must not touch it again */
+        pcamv_batch *b = c->member_of[k];
+        for (int i = 0; i < b->n; i++) if (b->ctx[i] == c) b->ctx[i] = NULL;
+    }
     for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
     hipFree(c->d_luma); hipFree(c->d_chroma[0]);
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
@@ -327,7 +344,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user);
     hipFree(c->d_nb_nz); hipFree(c->d_nb_cbp); hipFree(c->d_nb_mvd); hipFree(c->d_cabac); hipFree(c->d_cabac_tab); hipFree(c->d_dbg_hash);
     for (int q = 0; q < 52; q++) if (c->d_cabac_init[q]) hipFree(c->d_cabac_init[q]);
-    hipStreamDestroy(c->stream);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -420,11 +437,13 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     HIPCHKB(b, hipSetDevice(b->device));
     for (int i = 0; i < b->n; i++) {
         pcamv_ctx *c = b->ctx[i];
-        if ((what & 2) && c->prev_internal) {      /* this frame writes field pp, reads the field the previous frame wrote */
-            c->F.mv = c->pp ? c->d_mv_b : c->d_mv; c->F.ref8 = c->pp ? c->d_ref8_b : c->d_ref8;
-            c->F.prev_mv = c->pp ? c->d_mv : c->d_mv_b; c->F.prev_ref = c->pp ? c->d_ref8 : c->d_ref8_b;
-            c->pp ^= 1;
+        if (!c) return bfail(b, PCAMV_EINVAL, "context %d of the batch was closed", i);
+        if ((what & 2) && c->prev_internal) {      /* this frame writes the field the last analysis did not write, and reads that one */
+            const int wr = !c->last_field;
+            c->F.mv = wr ? c->d_mv_b : c->d_mv; c->F.ref8 = wr ? c->d_ref8_b : c->d_ref8;
+            c->F.prev_mv = wr ? c->d_mv : c->d_mv_b; c->F.prev_ref = wr ? c->d_ref8 : c->d_ref8_b;
         }
+        if (what & 2) c->last_field = c->F.mv == c->d_mv_b;
     }
     const FrameDev *dF; const EmbedDev *dE; int slot;
     int rc = batch_push_descs(b, st, &dF, &dE, &slot);
@@ -575,12 +594,13 @@ static int fetch_embed(pcamv_ctx *c, pcamv_embed_t *out)
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(hdr, c->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
     out->n = hdr[0]; out->m = hdr[1]; out->stc_ok = hdr[2]; out->num_flip = hdr[3];
-    if (out->n < 0 || out->m < 0 || out->n > c->cap || out->m > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
+    if (out->n < 0 || out->m < 0 || out->n > c->cap) return fail(c, PCAMV_EHIP, "embed header corrupt");
+    const int m_copy = out->m < c->cap ? out->m : c->cap;          /* a bits-per-frame rate above the capacity: stc_embed failed (m > n), the message array holds cap bits */
     if (out->cover && out->n) HIPCHK(c, hipMemcpy(out->cover, c->d_cover, out->n, hipMemcpyDeviceToHost));
     if (out->rho && out->n) HIPCHK(c, hipMemcpy(out->rho, c->d_rho, (size_t)out->n * 4, hipMemcpyDeviceToHost));
     if (out->stego && out->n) HIPCHK(c, hipMemcpy(out->stego, c->d_stego, out->n, hipMemcpyDeviceToHost));
     if (out->flip && out->n) HIPCHK(c, hipMemcpy(out->flip, c->d_flip, out->n, hipMemcpyDeviceToHost));
-    if (out->message && out->m) HIPCHK(c, hipMemcpy(out->message, c->d_message, out->m, hipMemcpyDeviceToHost));
+    if (out->message && m_copy) HIPCHK(c, hipMemcpy(out->message, c->d_message, m_copy, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -685,10 +705,12 @@ extern "C" int pcamv_gpu_batch_step(pcamv_batch_t *b, int qp, float emrate, void
     HIPCHKB(b, hipSetDevice(b->device));
     for (int i = 0; i < b->n; i++) {
         pcamv_ctx *c = b->ctx[i];
+        if (!c) return bfail(b, PCAMV_EINVAL, "context %d of the batch was closed", i);
         int rc = ensure_qp(c, qp);
         if (rc) return bfail(b, rc, "%s", c->err);
         if (!c->F.raw[0]) return bfail(b, PCAMV_EINVAL, "context %d has no reference", i);
         c->F.embed = emrate > 0; c->E.emrate = emrate; c->E.user_message = NULL; c->E.user_message_len = 0;
+        c->F.flip = c->d_flip;        /* a closed-loop step applies the flip map of its own embedding stage, never a caller's map left by pass2_pframe */
     }
     hipStream_t st = stream ? (hipStream_t)stream : b->ctx[0]->stream;
     return batch_launch(b, (emrate > 0 ? 7 : 3) | (b->closed_loop ? 8 : 0), st, 1);

@@ -525,7 +525,14 @@ static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa
 void pcamv_launch_flow_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 /* ... and so does the instance with the RD mode decision of --subme 6 / 7 (csrc/pcamv_rd.hip) */
 #ifdef PCAMV_RD_TU
-static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_rd(const FrameDev *__restrict__ Fs, FlowDev fl)
+/* register budget of this instance: with CABAC a frame is one chain of macroblocks, so a GPU runs one or two waves per SIMD at
+ * most (one chain per GOP in flight + the RCA work they hand off) and what counts is the time of a macroblock, not the
+ * occupancy: at the search kernel's 128 VGPRs this code spilled 192 registers to scratch (a memory round trip each for a
+ * lone wave); 2 waves per SIMD = 256 VGPRs */
+#ifndef PCAMV_RD_OCC
+#define PCAMV_RD_OCC 2
+#endif
+static __global__ void __launch_bounds__(64, PCAMV_RD_OCC) k_analyse_flow_rd(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
@@ -723,7 +730,7 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
     }
     if (t < 64) {
         if (E.user_message) {
-            for (int i = t; i < m; i += 64) E.message[i] = i < E.user_message_len ? E.user_message[i] : 0;
+            for (int i = t; i < imin(m, E.cap); i += 64) E.message[i] = i < E.user_message_len ? E.user_message[i] : 0;     /* m > n (> cap) fails in stc_embed like the reference's; never write past the arrays */
         } else {
             /* glibc TYPE_3 rand(): x[k] = x[k-31] + x[k-3], output x[k] >> 1.  Three outputs are independent of each
              * other, so lanes 0..2 make three per round on a 64-entry ring in LDS.  The stored state is a 31-entry
@@ -736,7 +743,7 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
                 if (t < 3 && k < m) {
                     const unsigned v = s_rnd[(k - 31) & 63] + s_rnd[(k - 3) & 63];
                     s_rnd[k & 63] = v;
-                    E.message[k] = (uint8_t)(v >> 1 & 1);
+                    if (k < E.cap) E.message[k] = (uint8_t)(v >> 1 & 1);      /* the stream advances by m whatever the capacity */
                 }
                 PCAMV_WAVE_SYNC();
             }

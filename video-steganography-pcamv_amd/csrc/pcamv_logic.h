@@ -666,69 +666,63 @@ PCAMV_DEV void intra_analyse(const FrameDev &F, MBLocal *L, int i_satd_inter, in
     if (idx == 15) *i4 = cost;
 }
 
-/* one CABAC decision on the context states S (LDS): every lane walks the same chain.  Table word = bits (8.8) << 8 | next state */
-PCAMV_DEV void cb_dec(MBLocal *L, uint8_t *S, int ctx, int b, int *bits)
-{
-    const uint32_t w = L_CTAB(L)[2 * S[ctx] + b];
-    S[ctx] = (uint8_t)(w & 255u);
-    *bits += (int)(w >> 8);
-}
-PCAMV_DEV void cb_mvd_cpn(MBLocal *L, uint8_t *S, int idx, int l, int mvd, int *bits)      /* encoder/cabac.c:403-449 */
+/* The CABAC walk of a macroblock goes through a CabWalk (primitives: on the GPU every context's state lives in the lane that
+ * owns it while the macroblock is walked; pcamv_prims_rd_gpu.h): prim_cab_begin, prim_cb_dec (one decision, context and bin
+ * wave-uniform), prim_cb_bypass, prim_cab_residual, prim_cab_end. */
+PCAMV_DEV void cb_mvd_cpn(MBLocal *L, CabWalk &C, int idx, int l, int mvd)      /* encoder/cabac.c:403-449 */
 {
     const int amvd = iabs(L->cmvd[scan8_of(idx) - 1][l]) + iabs(L->cmvd[scan8_of(idx) - 8][l]);
     const int a = iabs(mvd), base = l ? 47 : 40;
-    cb_dec(L, S, base + (amvd > 2) + (amvd > 32), a != 0, bits);
+    prim_cb_dec(L, C, base + (amvd > 2) + (amvd > 32), a != 0);
     if (!a) return;
-    for (int i = 1; i < imin(a, 9); i++) cb_dec(L, S, base + imin(i + 2, 6), 1, bits);      /* contexts 3, 4, 5, 6, 6, .. */
-    if (a < 9) cb_dec(L, S, base + imin(a + 2, 6), 0, bits);
-    else *bits += (size_ue_of((unsigned)(a - 9 + 7)) - 3) << 8;                              /* Exp-Golomb k = 3 suffix, bypass */
-    *bits += 256;                                                                           /* sign, bypass */
+    for (int i = 1; i < imin(a, 9); i++) prim_cb_dec(L, C, base + imin(i + 2, 6), 1);      /* contexts 3, 4, 5, 6, 6, .. */
+    if (a < 9) prim_cb_dec(L, C, base + imin(a + 2, 6), 0);
+    else prim_cb_bypass(C, (size_ue_of((unsigned)(a - 9 + 7)) - 3) << 8);                   /* Exp-Golomb k = 3 suffix */
+    prim_cb_bypass(C, 256);                                                                /* sign */
 }
-PCAMV_DEV void cb_mvd(MBLocal *L, uint8_t *S, int idx, int width, int height, int *bits)     /* encoder/cabac.c:452-470 */
+PCAMV_DEV void cb_mvd(MBLocal *L, CabWalk &C, int idx, int width, int height)     /* encoder/cabac.c:452-470 */
 {
     int mvp[2];
     predict_mv(L, idx, width, mvp);
     const int dx = L->cmv[scan8_of(idx)][0] - mvp[0], dy = L->cmv[scan8_of(idx)][1] - mvp[1];
-    cb_mvd_cpn(L, S, idx, 0, dx, bits);
-    cb_mvd_cpn(L, S, idx, 1, dy, bits);
+    cb_mvd_cpn(L, C, idx, 0, dx);
+    cb_mvd_cpn(L, C, idx, 1, dy);
     for (int j = 0; j < height; j++)
         for (int i = 0; i < width; i++) { L->cmvd[scan8_of(idx) + i + 8 * j][0] = (int16_t)dx; L->cmvd[scan8_of(idx) + i + 8 * j][1] = (int16_t)dy; }
 }
 /* macroblock layer of a P_L0 / P_8x8 macroblock up to the residual: mb_type, sub_mb_type, mvd, coded_block_pattern,
- * mb_qp_delta (0: constant QP, last delta 0).  Returns the bits in 8.8 fixed point. */
-PCAMV_DEV int cabac_mb_header(const FrameDev &F, MBLocal *L, uint8_t *S)
+ * mb_qp_delta (0: constant QP, last delta 0) */
+PCAMV_DEV void cabac_mb_header(const FrameDev &F, MBLocal *L, CabWalk &C)
 {
-    int bits = 0;
-    cb_dec(L, S, 14, 0, &bits);
-    if (L->i_type == PCAMV_P_8x8 || L->i_partition == PCAMV_D_16x16) { cb_dec(L, S, 15, 0, &bits); cb_dec(L, S, 16, L->i_type == PCAMV_P_8x8, &bits); }
-    else { cb_dec(L, S, 15, 1, &bits); cb_dec(L, S, 17, L->i_partition == PCAMV_D_16x8, &bits); }
+    prim_cb_dec(L, C, 14, 0);
+    if (L->i_type == PCAMV_P_8x8 || L->i_partition == PCAMV_D_16x16) { prim_cb_dec(L, C, 15, 0); prim_cb_dec(L, C, 16, L->i_type == PCAMV_P_8x8); }
+    else { prim_cb_dec(L, C, 15, 1); prim_cb_dec(L, C, 17, L->i_partition == PCAMV_D_16x8); }
     if (L->i_type == PCAMV_P_8x8) {
         for (int i = 0; i < 4; i++) {
             const int sp = L->sub_part[i];
-            cb_dec(L, S, 21, sp == PCAMV_D_L0_8x8, &bits);
-            if (sp != PCAMV_D_L0_8x8) { cb_dec(L, S, 22, sp != PCAMV_D_L0_8x4, &bits); if (sp != PCAMV_D_L0_8x4) cb_dec(L, S, 23, sp == PCAMV_D_L0_4x8, &bits); }
+            prim_cb_dec(L, C, 21, sp == PCAMV_D_L0_8x8);
+            if (sp != PCAMV_D_L0_8x8) { prim_cb_dec(L, C, 22, sp != PCAMV_D_L0_8x4); if (sp != PCAMV_D_L0_8x4) prim_cb_dec(L, C, 23, sp == PCAMV_D_L0_4x8); }
         }
         for (int i = 0; i < 4; i++)
             switch (L->sub_part[i]) {
-            case PCAMV_D_L0_8x8: cb_mvd(L, S, 4 * i, 2, 2, &bits); break;
-            case PCAMV_D_L0_8x4: cb_mvd(L, S, 4 * i, 2, 1, &bits); cb_mvd(L, S, 4 * i + 2, 2, 1, &bits); break;
-            case PCAMV_D_L0_4x8: cb_mvd(L, S, 4 * i, 1, 2, &bits); cb_mvd(L, S, 4 * i + 1, 1, 2, &bits); break;
-            default: for (int k = 0; k < 4; k++) cb_mvd(L, S, 4 * i + k, 1, 1, &bits); break;
+            case PCAMV_D_L0_8x8: cb_mvd(L, C, 4 * i, 2, 2); break;
+            case PCAMV_D_L0_8x4: cb_mvd(L, C, 4 * i, 2, 1); cb_mvd(L, C, 4 * i + 2, 2, 1); break;
+            case PCAMV_D_L0_4x8: cb_mvd(L, C, 4 * i, 1, 2); cb_mvd(L, C, 4 * i + 1, 1, 2); break;
+            default: for (int k = 0; k < 4; k++) cb_mvd(L, C, 4 * i + k, 1, 1); break;
             }
-    } else if (L->i_partition == PCAMV_D_16x16) cb_mvd(L, S, 0, 4, 4, &bits);
-    else if (L->i_partition == PCAMV_D_16x8) { cb_mvd(L, S, 0, 4, 2, &bits); cb_mvd(L, S, 8, 4, 2, &bits); }
-    else { cb_mvd(L, S, 0, 2, 4, &bits); cb_mvd(L, S, 4, 2, 4, &bits); }
+    } else if (L->i_partition == PCAMV_D_16x16) cb_mvd(L, C, 0, 4, 4);
+    else if (L->i_partition == PCAMV_D_16x8) { cb_mvd(L, C, 0, 4, 2); cb_mvd(L, C, 8, 4, 2); }
+    else { cb_mvd(L, C, 0, 2, 4); cb_mvd(L, C, 4, 2, 4); }
     const int cbp = L->cbp_luma, cl = L->cbp_left, ct = L->cbp_top;
-    cb_dec(L, S, 76 - ((cl >> 1) & 1) - ((ct >> 1) & 2), cbp & 1, &bits);
-    cb_dec(L, S, 76 - (cbp & 1) - ((ct >> 2) & 2), (cbp >> 1) & 1, &bits);
-    cb_dec(L, S, 76 - ((cl >> 3) & 1) - ((cbp << 1) & 2), (cbp >> 2) & 1, &bits);
-    cb_dec(L, S, 76 - ((cbp >> 2) & 1) - (cbp & 2), (cbp >> 3) & 1, &bits);
+    prim_cb_dec(L, C, 76 - ((cl >> 1) & 1) - ((ct >> 1) & 2), cbp & 1);
+    prim_cb_dec(L, C, 76 - (cbp & 1) - ((ct >> 2) & 2), (cbp >> 1) & 1);
+    prim_cb_dec(L, C, 76 - ((cl >> 3) & 1) - ((cbp << 1) & 2), (cbp >> 2) & 1);
+    prim_cb_dec(L, C, 76 - ((cbp >> 2) & 1) - (cbp & 2), (cbp >> 3) & 1);
     const int ca = cl & 0x30, cb = ct & 0x30;
-    cb_dec(L, S, 77 + ((ca && cl != -1) ? 1 : 0) + ((cb && ct != -1) ? 2 : 0), L->cbp_chroma != 0, &bits);
-    if (L->cbp_chroma) cb_dec(L, S, 77 + 4 + (ca == 0x20) + 2 * (cb == 0x20), L->cbp_chroma > 1, &bits);
-    if (L->cbp_luma | L->cbp_chroma) cb_dec(L, S, 60, 0, &bits);
+    prim_cb_dec(L, C, 77 + ((ca && cl != -1) ? 1 : 0) + ((cb && ct != -1) ? 2 : 0), L->cbp_chroma != 0);
+    if (L->cbp_chroma) prim_cb_dec(L, C, 77 + 4 + (ca == 0x20) + 2 * (cb == 0x20), L->cbp_chroma > 1);
+    if (L->cbp_luma | L->cbp_chroma) prim_cb_dec(L, C, 60, 0);
     (void)F;
-    return bits;
 }
 /* x264_rd_cost_mb (rdo.c:139-171) of the macroblock as the cache describes it: distortion (SSD + psy-RD) + lambda2 * bits */
 PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
@@ -743,11 +737,13 @@ PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
     int bits;
     if (F.b_cabac) {
         const unsigned long long t_h = PROF_T();
-        prim_cabac_trial_begin(L);                           /* trial copy of the macroblock-header contexts */
-        int f8 = cabac_mb_header(F, L, L_CAB(L, 1));
+        CabWalk C;
+        prim_cab_begin(L, C);                                /* a size trial: the slice's states are read, never written */
+        cabac_mb_header(F, L, C);
         PROF_ADD(20, t_h);
         const unsigned long long t_r = PROF_T();
-        f8 += prim_cabac_residual(F, L, 0);
+        prim_cab_residual(F, L, C, 0);
+        const int f8 = prim_cab_end(L, C, 0);
         PROF_ADD(21, t_r);
         bits = (int)(((unsigned long long)(unsigned)f8 * (unsigned long long)F.lambda2 + 32768ull) >> 16);
     } else
@@ -770,10 +766,11 @@ PCAMV_DEV void entropy_commit(const FrameDev &F, MBLocal *L)
 {
     const int skip = L->i_type == PCAMV_P_SKIP;
     if (F.b_cabac) {
-        int bits = 0;
-        uint8_t *S = L_CAB(L, 0);
-        cb_dec(L, S, 11 + (L->type_left >= 0 && L->type_left != PCAMV_P_SKIP) + (L->type_top >= 0 && L->type_top != PCAMV_P_SKIP), skip, &bits);   /* x264_cabac_mb_skip */
-        if (!skip) { cabac_mb_header(F, L, S); prim_cabac_residual(F, L, 1); }
+        CabWalk C;
+        prim_cab_begin(L, C);
+        prim_cb_dec(L, C, 11 + (L->type_left >= 0 && L->type_left != PCAMV_P_SKIP) + (L->type_top >= 0 && L->type_top != PCAMV_P_SKIP), skip);   /* x264_cabac_mb_skip */
+        if (!skip) { cabac_mb_header(F, L, C); prim_cab_residual(F, L, C, 1); }
+        prim_cab_end(L, C, 1);                               /* the macroblock as coded: the adapted states are the slice's */
     } else if (!skip) prim_cavlc_mb(F, L);
     prim_rd_commit(F, L, skip);
 }

@@ -406,95 +406,192 @@ __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
     return ssd;
 }
 
-/* ---------------------------------------------------------------- CABAC size / context walk of the residual */
-__device__ __forceinline__ void prim_cabac_trial_begin(MBLocal *L)
+/* ---------------------------------------------------------------- CABAC size / context walk of a macroblock */
+/* While a macroblock is walked, the state of every context it can touch lives in the lane that owns it: header contexts
+ * 0..87 (mb_skip, mb_type, sub_mb_type, mvd, mb_qp_delta, coded_block_pattern) in lane ctx & 63 (two registers), the
+ * residual contexts per block category as described at prim_cab_residual.  A decision is one table lookup (bits << 8 | next
+ * state) by the owning lane; the bits are summed per lane and over the wave at the end.  The slice's states (LDS) are read
+ * at the beginning and written back only by the committing walk. */
+struct CabWalk { int s0, s1, t0, t1, t2, t3, bits, vbits; };
+/* The walk's sequential decisions (macroblock header, level chains) run on the scalar side: the state is read out of its lane
+ * (v_readlane), the (bits << 8 | next state) word comes out of the table held in four registers across the wave (entry e in
+ * lane e & 63 of register e >> 6), the new state goes back with v_writelane, the bits add up in a scalar -- no memory round
+ * trip on the chain (an LDS lookup per decision measured ~1500 cycles per coded block for a lone wave). */
+/* v_writelane by hand (this compiler has no builtin for it; in inline assembly it trips over the constant-bus rule): a compare +
+ * select over the wave, the value coming from a scalar */
+__device__ __forceinline__ int lane_set(int old, int val, int lane_idx) { return LANE() == lane_idx ? val : old; }
+__device__ __forceinline__ uint32_t cab_tab(const CabWalk &C, int e)
+{
+    const int l = e & 63;
+    const int a = __builtin_amdgcn_readlane(C.t0, l), b = __builtin_amdgcn_readlane(C.t1, l), c = __builtin_amdgcn_readlane(C.t2, l), d = __builtin_amdgcn_readlane(C.t3, l);
+    return (uint32_t)(e < 64 ? a : e < 128 ? b : e < 192 ? c : d);
+}
+__device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    if (lane < 22) ((uint32_t *)L_CAB(L, 1))[lane] = ((const uint32_t *)L_CAB(L, 0))[lane];      /* contexts 0..87: the macroblock header's */
-    PCAMV_WAVE_SYNC();
+    const uint8_t *S = L_CAB(L, 0);
+    const uint32_t *T = L_CTAB(L);
+    C.s0 = S[lane]; C.s1 = lane < 24 ? S[64 + lane] : 0; C.bits = 0; C.vbits = 0;
+    C.t0 = (int)T[lane]; C.t1 = (int)T[64 + lane]; C.t2 = (int)T[128 + lane]; C.t3 = (int)T[192 + lane];
 }
-/* Bits (8.8) of coded_block_flag + significance map + levels of every coded block, in coding order (luma 4x4 blocks of the
- * coded 8x8s, chroma DC, chroma AC).  The contexts of a category are held in lane registers while its blocks are walked:
- * lane i owns significant_coeff_flag[i] and last_significant_coeff_flag[i], lane k < 10 owns coeff_abs_level_minus1 context
- * k, lane k < 4 owns coded_block_flag increment k.  commit: write the adapted states back (the macroblock as coded);
- * otherwise this is a size trial and the states are only read. */
-__device__ __forceinline__ int prim_cabac_residual(const FrameDev &F, MBLocal *L, int commit_)
+__device__ __forceinline__ void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx_, int b_)
+{
+    const int ctx = rfl(ctx_), b = rfl(b_);
+    (void)L;
+    if (ctx < 64) {
+        const uint32_t w = cab_tab(C, 2 * __builtin_amdgcn_readlane(C.s0, ctx) + b);
+        C.bits += (int)(w >> 8);
+        C.s0 = lane_set(C.s0, (int)(w & 255u), ctx);
+    } else {
+        const uint32_t w = cab_tab(C, 2 * __builtin_amdgcn_readlane(C.s1, ctx - 64) + b);
+        C.bits += (int)(w >> 8);
+        C.s1 = lane_set(C.s1, (int)(w & 255u), ctx - 64);
+    }
+}
+__device__ __forceinline__ void prim_cb_bypass(CabWalk &C, int f8) { C.bits += rfl(f8); }
+__device__ __forceinline__ int prim_cab_end(MBLocal *L, CabWalk &C, int commit_)
+{
+    const int lane = LANE();
+    if (rfl(commit_)) {
+        uint8_t *S = L_CAB(L, 0);
+        S[lane] = (uint8_t)C.s0;
+        if (lane < 24) S[64 + lane] = (uint8_t)C.s1;
+    }
+    const int total = rfl(C.bits) + wave_sum_all(C.vbits);
+    PCAMV_WAVE_SYNC();
+    return total;
+}
+/* coded_block_flag + significance map + levels of every coded block (encoder/cabac.c:540-667, 1000-1018), three steps:
+ *  1. one block per lane (0..15 luma 4x4, 16..23 chroma AC, 24 / 25 chroma DC): is it coded (coded_block_pattern), its
+ *     coded_block_flag and that flag's context increment (left / top neighbours), its levels as bit masks (non-zero, above 1)
+ *     and 4-bit magnitudes -- one round of LDS reads for the whole macroblock;
+ *  2. the coded_block_flag chains, one context per lane (3 categories x 4 increments), each lane walking the blocks that use it;
+ *  3. per category, the blocks with levels in coding order: lane i owns significant_coeff_flag[i] and last_significant_
+ *     coeff_flag[i] (one decision each per block, all positions at once), lane k < 10 owns coeff_abs_level_minus1 context k
+ *     and takes the level chain's decisions as they come (non-zero levels only, from the last one down).
+ * The per-block values of step 1 reach the wave-uniform control code of steps 2 / 3 through ballots and v_readlane. */
+__device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit_)
 {
     const int commit = rfl(commit_);
     const int lane = LANE();
     PCAMV_WAVE_SYNC();
     const int cbp_luma = rfl(L->cbp_luma), cbp_chroma = rfl(L->cbp_chroma);
-    int bits = 0;
+    (void)F;
+    if (!(cbp_luma | cbp_chroma)) return;
     uint8_t *S = L_CAB(L, 0);
     const uint32_t *T = L_CTAB(L);
-    if (cbp_luma | cbp_chroma)
-        for (int pass = 0; pass < 3; pass++) {
-            if (pass == 1 && !(cbp_chroma & 3)) continue;
-            if (pass == 2 && !(cbp_chroma & 2)) continue;
-            if (pass == 0 && !cbp_luma) continue;
-            const int cat = 2 + pass, first = pass == 0 ? 0 : pass == 1 ? 25 : 16, nb = pass == 0 ? 16 : pass == 1 ? 2 : 8, count = pass == 0 ? 16 : pass == 1 ? 4 : 15;
-            const int sig_off = pass == 0 ? 134 : pass == 1 ? 149 : 152, last_off = pass == 0 ? 195 : pass == 1 ? 210 : 213, lvl_off = pass == 0 ? 247 : pass == 1 ? 257 : 266;
-            int sigS = lane < count - 1 ? S[sig_off + lane] : 0, lastS = lane < count - 1 ? S[last_off + lane] : 0;
-            int lvlS = lane < 10 ? S[lvl_off + lane] : 0, cbfS = lane < 4 ? S[85 + 4 * cat + lane] : 0;
-            for (int k = 0; k < nb; k++) {
-                const int idx = first + k;
-                if (pass == 0 && !(cbp_luma & (1 << (k >> 2)))) continue;
-                int inc;
-                if (pass == 1) {
-                    const int cl = L->cbp_left, ct = L->cbp_top;
-                    inc = (cl != -1 ? (cl >> (9 + k)) & 1 : 0) + 2 * (ct != -1 ? (ct >> (9 + k)) & 1 : 0);
-                } else {
-                    const int p8 = scan8_all_of(idx);
-                    inc = ((L->nzc[p8 - 1] & 0x7f) != 0) + 2 * ((L->nzc[p8 - 8] & 0x7f) != 0);
-                }
-                inc = rfl(inc);
-                const int flag = rfl(L->nzc[scan8_all_of(idx)] != 0);
-                if (lane == inc) { const uint32_t w = T[2 * cbfS + flag]; bits += (int)(w >> 8); cbfS = (int)(w & 255u); }
-                if (!flag) continue;
-                int lv = 0;
-                if (lane < count) lv = pass == 1 ? L->cdc[k][lane] : pass == 2 ? L->coef[idx][lane + 1] : L->coef[idx][lane];
-                const unsigned nzm = (unsigned)__ballot(lv != 0), gt1m = (unsigned)__ballot(iabs(lv) > 1);
-                if (!nzm) continue;                       /* cannot happen for a block flagged non-zero */
-                const int last = 31 - __builtin_clz(nzm);
-                if (lane < imin(last + 1, count - 1)) {
-                    uint32_t w = T[2 * sigS + (lv != 0)]; bits += (int)(w >> 8); sigS = (int)(w & 255u);
-                    if (lv != 0) { w = T[2 * lastS + (lane == last)]; bits += (int)(w >> 8); lastS = (int)(w & 255u); }
-                }
-                /* levels, from the last non-zero one down: node = min(#(|l| = 1) so far, 3) until a level above 1 was seen, then min(3 + #(|l| > 1), 7) */
-                int neq1 = 0, ngt1 = 0;
-                const int alv = iabs(lv);
-                for (unsigned m = nzm; m;) {
-                    const int i = 31 - __builtin_clz(m);
-                    m &= ~(1u << i);
-                    const int node = ngt1 ? imin(3 + ngt1, 7) : imin(neq1, 3);
-                    const int c1 = node < 4 ? node + 1 : 0, c2 = node < 4 ? 5 : imin(node + 2, 9);
-                    if ((gt1m >> i) & 1u) {
-                        const int am1 = __builtin_amdgcn_readlane(alv, i) - 1, prefix = imin(am1, 14);
-                        if (lane == c1) { const uint32_t w = T[2 * lvlS + 1]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
-                        if (lane == c2) {
-                            for (int q = 0; q < prefix - 1; q++) { const uint32_t w = T[2 * lvlS + 1]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
-                            if (prefix < 14) { const uint32_t w = T[2 * lvlS]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
-                        }
-                        if (prefix >= 14 && lane == 0) bits += size_ue_of((unsigned)(am1 - 14)) << 8;
-                        ngt1++;
-                    } else {
-                        if (lane == c1) { const uint32_t w = T[2 * lvlS]; bits += (int)(w >> 8); lvlS = (int)(w & 255u); }
-                        neq1++;
+    int bits = 0, sbits = 0;            /* per-lane bits (map decisions, coded_block_flag chains) / wave-uniform bits (level chains) */
+    const unsigned long long t_1 = PROF_T();
+    /* ---- 1 */
+    const bool coded = lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) != 0 : lane < 24 ? (cbp_chroma & 2) != 0 : lane < 26 ? (cbp_chroma & 3) != 0 : false;
+    const int idx = lane < 24 ? lane : lane < 26 ? 25 + (lane - 24) : 0;
+    const int count = lane < 16 ? 16 : lane < 24 ? 15 : 4;
+    int flag = 0, inc = 0;
+    unsigned nzm = 0, gt1 = 0, nib0 = 0, nib1 = 0;
+    if (coded) {
+        const int p8 = scan8_all_of(idx);
+        flag = L->nzc[p8] != 0;
+        if (lane >= 24) {
+            const int cl = L->cbp_left, ct = L->cbp_top, k = lane - 24;
+            inc = (cl != -1 ? (cl >> (9 + k)) & 1 : 0) + 2 * (ct != -1 ? (ct >> (9 + k)) & 1 : 0);
+        } else inc = ((L->nzc[p8 - 1] & 0x7f) != 0) + 2 * ((L->nzc[p8 - 8] & 0x7f) != 0);
+        if (flag) {
+            const uint32_t *w = lane < 24 ? (const uint32_t *)L->coef[lane] : (const uint32_t *)L->cdc[lane - 24];
+            const int nw = lane < 24 ? 8 : 2, sh = (lane >= 16 && lane < 24) ? 1 : 0;       /* chroma AC: scan position i is raw[i + 1] */
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t v = j < nw ? w[j] : 0u;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int lv = (int)(int16_t)(v >> (16 * h)), pos = 2 * j + h - sh;
+                    if (pos >= 0 && lv) {
+                        const int a = imin(iabs(lv), 15);
+                        nzm |= 1u << pos; gt1 |= (unsigned)(a > 1) << pos;
+                        if (pos < 8) nib0 |= (unsigned)a << (4 * pos); else nib1 |= (unsigned)a << (4 * (pos - 8));
                     }
-                    if (lane == 0) bits += 256;       /* sign */
                 }
-            }
-            if (commit) {
-                if (lane < count - 1) { S[sig_off + lane] = (uint8_t)sigS; S[last_off + lane] = (uint8_t)lastS; }
-                if (lane < 10) S[lvl_off + lane] = (uint8_t)lvlS;
-                if (lane < 4) S[85 + 4 * cat + lane] = (uint8_t)cbfS;
             }
         }
-    const int total = wave_sum_all(bits);
-    (void)F;
-    PCAMV_WAVE_SYNC();
-    return total;
+    }
+    const unsigned codedm = (unsigned)__ballot(coded), flagm = (unsigned)__ballot(flag != 0 && nzm != 0);
+    const unsigned inc_lo = (unsigned)__ballot(coded && (inc & 1)), inc_hi = (unsigned)__ballot(coded && (inc & 2));
+    PROF_ADD(24, t_1);
+    PROF_CNT(27, 1); PROF_CNT(28, __builtin_popcount(flagm)); PROF_CNT(29, __builtin_popcount(codedm));
+    const unsigned long long t_2 = PROF_T();
+    /* ---- 2: lane = 4 * category + increment (categories luma 4x4, chroma DC, chroma AC = block bits 0..15, 24..25, 16..23) */
+    if (lane < 12) {
+        const int cat = lane >> 2, k = lane & 3;
+        const unsigned catm = cat == 0 ? 0xffffu : cat == 1 ? 0x3000000u : 0xff0000u;
+        const unsigned same = ~(inc_lo ^ (0u - (unsigned)(k & 1))) & ~(inc_hi ^ (0u - (unsigned)(k >> 1)));
+        int st = S[85 + 4 * (2 + cat) + k];
+        for (unsigned m = codedm & catm & same; m; m &= m - 1) {
+            const int b = __builtin_ctz(m);
+            const uint32_t w = T[2 * st + (int)((flagm >> b) & 1u)];
+            bits += (int)(w >> 8); st = (int)(w & 255u);
+        }
+        if (commit) S[85 + 4 * (2 + cat) + k] = (uint8_t)st;
+    }
+    PROF_ADD(25, t_2);
+    const unsigned long long t_3 = PROF_T();
+    /* ---- 3 */
+    for (int pass = 0; pass < 3; pass++) {
+        const unsigned catm = pass == 0 ? 0xffffu : pass == 1 ? 0x3000000u : 0xff0000u;
+        unsigned bm = flagm & catm;
+        if (!bm) continue;
+        const int cnt = pass == 0 ? 16 : pass == 1 ? 4 : 15;
+        const int sig_off = pass == 0 ? 134 : pass == 1 ? 149 : 152, last_off = pass == 0 ? 195 : pass == 1 ? 210 : 213, lvl_off = pass == 0 ? 247 : pass == 1 ? 257 : 266;
+        int sigS = lane < cnt - 1 ? S[sig_off + lane] : 0, lastS = lane < cnt - 1 ? S[last_off + lane] : 0, lvlS = lane < 10 ? S[lvl_off + lane] : 0;
+        for (; bm; bm &= bm - 1) {
+            const int b = __builtin_ctz(bm);
+            const unsigned nz = (unsigned)__builtin_amdgcn_readlane((int)nzm, b), g1 = (unsigned)__builtin_amdgcn_readlane((int)gt1, b);
+            const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nib0, b), n1 = (unsigned)__builtin_amdgcn_readlane((int)nib1, b);
+            const int last = 31 - __builtin_clz(nz);
+            if (lane < imin(last + 1, cnt - 1)) {
+                const int sb = (int)((nz >> lane) & 1u);
+                const uint32_t w1 = T[2 * sigS + sb], w2 = T[2 * lastS + (lane == last)];
+                bits += (int)(w1 >> 8); sigS = (int)(w1 & 255u);
+                if (sb) { bits += (int)(w2 >> 8); lastS = (int)(w2 & 255u); }
+            }
+            /* levels from the last non-zero one down: node = min(#(|l| = 1) so far, 3) until a level above 1 was seen, then min(3 + #(|l| > 1), 7) */
+            int neq1 = 0, ngt1 = 0;
+            for (unsigned m = nz; m;) {
+                const int i = 31 - __builtin_clz(m);
+                m &= ~(1u << i);
+                const int node = ngt1 ? imin(3 + ngt1, 7) : imin(neq1, 3);
+                const int c1 = node < 4 ? node + 1 : 0, c2 = node < 4 ? 5 : imin(node + 2, 9);
+                int st1 = __builtin_amdgcn_readlane(lvlS, c1);
+                if ((g1 >> i) & 1u) {
+                    int a = (int)(((i < 8 ? n0 : n1) >> (4 * (i & 7))) & 15u);
+                    if (a == 15) {          /* 15 or more: the exact magnitude (escape suffix) from the block's levels */
+                        const int16_t *l = b < 16 ? L->coef[b] : b < 24 ? L->coef[b] + 1 : L->cdc[b - 24];
+                        a = rfl(iabs((int)l[i]));
+                    }
+                    const int am1 = a - 1, prefix = imin(am1, 14);
+                    uint32_t w = cab_tab(C, 2 * st1 + 1);
+                    sbits += (int)(w >> 8); lvlS = lane_set(lvlS, (int)(w & 255u), c1);
+                    int st2 = __builtin_amdgcn_readlane(lvlS, c2);
+                    for (int q = 0; q < prefix - 1; q++) { w = cab_tab(C, 2 * st2 + 1); sbits += (int)(w >> 8); st2 = (int)(w & 255u); }
+                    if (prefix < 14) { w = cab_tab(C, 2 * st2); sbits += (int)(w >> 8); st2 = (int)(w & 255u); }
+                    else sbits += size_ue_of((unsigned)(am1 - 14)) << 8;
+                    lvlS = lane_set(lvlS, st2, c2);
+                    ngt1++;
+                } else {
+                    const uint32_t w = cab_tab(C, 2 * st1);
+                    sbits += (int)(w >> 8); lvlS = lane_set(lvlS, (int)(w & 255u), c1);
+                    neq1++;
+                }
+            }
+            sbits += 256 * __builtin_popcount(nz);       /* signs */
+            PROF_CNT(30, __builtin_popcount(nz));
+        }
+        if (commit) {
+            if (lane < cnt - 1) { S[sig_off + lane] = (uint8_t)sigS; S[last_off + lane] = (uint8_t)lastS; }
+            if (lane < 10) S[lvl_off + lane] = (uint8_t)lvlS;
+        }
+    }
+    PROF_ADD(26, t_3);
+    C.vbits += bits; C.bits += sbits;
 }
 
 /* ---------------------------------------------------------------- CAVLC size of the macroblock layer */

@@ -26,8 +26,8 @@ int pcamv_flow_rd_waves_per_cu(void)
 /* the phase timers are per translation unit (static __device__): this instance's */
 int pcamv_rd_prof_fetch(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
