@@ -3,74 +3,140 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one P frame through the whole hot path (half-pel plane production, motion search +
-partition decision, RCA replacement-MV costs, pass-1 reconstruction, cover/cost assembly,
-syndrome-trellis embedding, then the reference's second pass: final MVs, reconstruction and loop
-filter, whose output is the next step's reference -- `--open-loop` stops before the second pass and
-searches against the previous source frame) for each of --gops independent closed GOPs resident on the GPU
-(closed GOPs are the reference's natural sharding unit; inside a frame the raster
-dependency leaves most of the chip idle, so one GPU advances many GOP pipelines together, each
-kernel launch carrying the same dependency step of all of them).  Inputs (synthetic 1080p I420, SURVEY 8(d) generator) are resident in HBM before the
-timed region.  N > 1: one process per GPU, GOPs sharded across ranks, no data-path collective
-(weak scaling); a summary all_gather over RCCL runs after the timed region.
+The workload is BASELINE.json's configuration 3 as written: 1920x1088 synthetic I420, --me umh --subme 7 (RD mode decision,
+CABAC, psy-RD: the reference's defaults at that level) --qp 26 --emrate 0.5, closed loop.
 
-Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus `roofline` for the dominant
-kernel (k_analyse_flow; k_search_diag under PCAMV_SCHED=diag) and `cpu_baseline` (the oracle port on a bounded sample, rank 0, N=1 only).
+A step = one P frame through the whole hot path (half-pel plane production, motion search + partition decision with the RD
+mode decision, RCA replacement-MV costs, pass-1 reconstruction, cover/cost assembly, syndrome-trellis embedding, then the
+reference's second pass: final MVs, reconstruction and loop filter, whose output is the next step's reference) for each of
+--gops independent closed GOPs resident on the GPU.  Closed GOPs are the reference's natural sharding unit; with
+CABAC a frame is one serial chain of macroblocks (the context states), so a GPU advances many GOP chains together, each launch
+carrying the same step of all of them.  Inputs are resident in HBM before the timed region.
+
+N > 1: one process per GPU (the driver launches them with torch.distributed.run; run by hand with --gpus N and no WORLD_SIZE in
+the environment, bench.py launches its N ranks itself).  Weak scaling (default): every rank runs --gops GOPs, no data-path
+collective.  --strong: --gops is the size of ONE fixed set of GOPs, sharded round-robin over the ranks (pcamv_amd.shard), and
+after the timed region payloads are gathered to rank 0 in GOP order with tensor collectives over RCCL.
+
+Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, `roofline` for the dominant kernel, `cpu_baseline` (the
+oracle port on a bounded 1080p sample + the reference itself, oracle/_ref, on CIF with the port beside it), and -- labelled
+extras, never `value` -- `pcie_inclusive` (the same steps with every frame's pictures uploaded and its results downloaded,
+overlapped with the compute) and `g_sweep` (throughput against the number of GOPs in flight).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "video-steganography-pcamv_amd"))
 
+B_SEARCH = 1920.0       # SURVEY 8(d): algorithmic bytes per macroblock of one analysis pass (source 384 + reference window 1152 + record/motion 384)
+B_WHOLE = 5888.0        # ... of both passes of the closed loop: 2 x (1920 + 1024)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
+MB_RECORD = 236         # sizeof(pcamv_mb_t)
 
-def main():
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gops", type=int, default=256, help="closed GOPs in flight per GPU (batched into every launch)")
+    ap.add_argument("--gops", type=int, default=4096, help="closed GOPs in flight per GPU (with --strong: in total); 35 MB of HBM each at 1080p")
+    ap.add_argument("--strong", action="store_true", help="one fixed set of --gops GOPs sharded over the ranks; payload gather after the timed region")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088, help="coded height (1080 rounded up to 16)")
     ap.add_argument("--me", default="umh")
     ap.add_argument("--subme", type=int, default=7)
+    ap.add_argument("--no-cabac", action="store_true")
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--emrate", type=float, default=0.5)
     ap.add_argument("--open-loop", action="store_true", help="pass 1 only: no pass 2 / loop filter, the reference is the previous source frame")
-    ap.add_argument("--closed-loop", action="store_true", help="(default) pass 2 + loop filter on the GPU, the deblocked reconstruction is the next reference")
-    ap.add_argument("--host-io-steps", type=int, default=3, help="extra untimed-for-`value` steps that also move each frame's source pictures host->device (pinned) and its records + embedding vectors device->host, reported as `pcie_inclusive` (0 = skip; rank 0, N=1 only)")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="P frames timed for the CPU baseline (0 = skip)")
-    args = ap.parse_args()
-    args.closed_loop = not args.open_loop
+    ap.add_argument("--host-io-steps", type=int, default=2, help="steps of the PCIe-inclusive pipeline (0 = skip; rank 0, N=1 only)")
+    ap.add_argument("--g-sweep", default="1,8,20,64,256", help="GOP counts of the low-G sweep ('' = skip; rank 0, N=1 only)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="1080p P frames timed for the CPU baseline (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-cif-frames", type=int, default=200, help="CIF P frames timed through the reference itself (oracle/_ref) and through the port (0 = skip)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N by hand: start the N ranks the way the driver does and pass rank 0's line through (nothing here has touched the GPU)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Gops:
+    """closed-GOP pipelines on one device: contexts + batch + the step function.  phases[k] = position of GOP k in the clip cycle"""
+
+    def __init__(self, pcamv_amd, params, dframes, phases, device, closed_loop):
+        self.dframes, self.closed, self.phases = dframes, closed_loop, list(phases)
+        self.encs = [pcamv_amd.Encoder(params, device=device) for _ in self.phases]
+        self.batch = pcamv_amd.Batch(self.encs)
+        if closed_loop:
+            self.batch.set_closed_loop(True)
+        self.recon = [e.recon_device() for e in self.encs]
+        self.started = False
+
+    def step(self, t, qp, emrate, stream, fenc_of=None):
+        nfr = len(self.dframes)
+        for k, enc in enumerate(self.encs):
+            ph = self.phases[k]
+            if self.closed and self.started:     # reference = this GOP's own deblocked reconstruction of the previous step, chained MV field
+                enc.set_ref_device(self.recon[k][0], self.recon[k][1], self.recon[k][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            else:
+                a = self.dframes[(t + ph) % nfr]
+                enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            b = fenc_of(k) if fenc_of else [pl.data_ptr() for pl in self.dframes[(t + ph + 1) % nfr]]
+            enc.set_fenc_device(b[0], b[1], b[2])
+        self.batch.step(qp, emrate, stream)
+        self.started = True
+
+    def close(self):
+        self.batch.close()
+        for e in self.encs:
+            e.close()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    closed_loop = not args.open_loop
 
     import numpy as np
     import torch
     import pcamv_amd
     from pcamv_amd.synth import make_clip
+    from pcamv_amd.shard import gop_assignment, gather_payloads, pack_gop_payload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     # rehearsal on a one-GPU box only: PCAMV_BENCH_REHEARSE=1 puts every rank on GPU 0 and runs the (untimed)
     # collectives over gloo, since RCCL refuses two ranks on one device; the driver's runs use RCCL, one GPU per rank
     rehearse = os.environ.get("PCAMV_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if rehearse else dev          # where collective operands live
 
@@ -79,33 +145,26 @@ def main():
     p = pcamv_amd.param_default(W, H)
     pcamv_amd.param_parse(p, "me", args.me)
     pcamv_amd.param_parse(p, "subme", args.subme)
+    if args.no_cabac:
+        pcamv_amd.param_parse(p, "no-cabac", 1)
 
-    # synthetic clip: a few distinct frames per GOP, cycled; each GOP gets its own phase of the clip
-    nfr = 6
-    clip = make_clip(W, H, nfr, seed=13 + rank)
+    # the GOPs of this rank: weak = --gops each; strong = this rank's share of one fixed set.  GOP g starts at phase g of the clip.
+    if args.strong:
+        mine = gop_assignment(args.gops, world, rank)
+        total_gops = args.gops
+    else:
+        mine = list(range(rank * args.gops, (rank + 1) * args.gops))
+        total_gops = args.gops * world
+    G = len(mine)
+    if G < 1:
+        sys.exit(f"rank {rank}: no GOP to run (--strong --gops {args.gops} over {world} ranks)")
+
+    nfr = 6                                                  # synthetic clip (SURVEY 8(d) generator): a few distinct frames, cycled
+    clip = make_clip(W, H, nfr, seed=13)
     dframes = [[torch.from_numpy(pl).to(dev) for pl in fr] for fr in clip]
-    encs = [pcamv_amd.Encoder(p, device=local) for _ in range(args.gops)]
-    batch = pcamv_amd.Batch(encs)          # all GOPs advance together: one launch per dependency step
-    if args.closed_loop:
-        batch.set_closed_loop(True)
-    recon = [enc.recon_device() for enc in encs]
-    started = [False]
+    run = Gops(pcamv_amd, p, dframes, mine, local, closed_loop)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
-
-    def step(t):
-        for g, enc in enumerate(encs):
-            a = dframes[(t + g) % nfr]
-            b = dframes[(t + g + 1) % nfr]
-            # reference = previous source frame (open loop: the deblocked pass-2 reconstruction that
-            # closes the loop in the encoder is produced by the host), chained MV field
-            if args.closed_loop and started[0]:     # reference = this GOP's own deblocked reconstruction of the previous step
-                enc.set_ref_device(recon[g][0], recon[g][1], recon[g][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
-            else:
-                enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
-            enc.set_fenc_device(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr())
-        batch.step(args.qp, args.emrate, stream.cuda_stream)
-        started[0] = True
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,164 +173,266 @@ def main():
         torch.cuda.synchronize()
 
     for t in range(args.warmup):
-        step(t)
+        run.step(t, args.qp, args.emrate, stream.cuda_stream)
     barrier()
-    batch.kernel_time(reset=True)
+    run.batch.kernel_time(reset=True)
     prof = None
     if os.environ.get("PCAMV_PROF_DUMP") == "1":      # diagnostics build of the library (-DPCAMV_PROF): wave cycles per phase
         import ctypes
-        prof = (ctypes.c_ulonglong * 32)()
+        prof = (ctypes.c_ulonglong * 48)()
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 1)
     t0 = time.perf_counter()
     for t in range(args.steps):
-        step(args.warmup + t)
+        run.step(args.warmup + t, args.qp, args.emrate, stream.cuda_stream)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    t_next = args.warmup + args.steps
 
-    # the same steps with the boundary's host traffic inside the timed region: source frame up (pinned, async on the step's
-    # stream), per-macroblock records + embedding vectors down (the C ABI's blocking fetch); nothing is overlapped
-    hio = None
-    if rank == 0 and world == 1 and args.host_io_steps > 0:
-        hsrc = [[pl.cpu().pin_memory() for pl in fr] for fr in dframes]
-        dstage = [[torch.empty_like(pl) for pl in dframes[0]] for _ in encs]
-        down = 0
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for t in range(args.host_io_steps):
-            tt = args.warmup + args.steps + t
-            with torch.cuda.stream(stream):
-                for g in range(len(encs)):
-                    for dst, src in zip(dstage[g], hsrc[(tt + g + 1) % nfr]):
-                        dst.copy_(src, non_blocking=True)
-            for g, enc in enumerate(encs):
-                if args.closed_loop:
-                    enc.set_ref_device(recon[g][0], recon[g][1], recon[g][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
-                else:
-                    a = dframes[(tt + g) % nfr]
-                    enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
-                enc.set_fenc_device(dstage[g][0].data_ptr(), dstage[g][1].data_ptr(), dstage[g][2].data_ptr())
-            batch.step(args.qp, args.emrate, stream.cuda_stream)
-            for enc in encs:
-                m_h, e_h = enc.fetch_results(want_embed=True)
-                down += m_h.nbytes + sum(np.asarray(v).nbytes for v in e_h.values() if hasattr(v, "nbytes"))
-        torch.cuda.synchronize()
-        dth = time.perf_counter() - t1
-        up = sum(pl.numel() for pl in hsrc[0]) * len(encs) * args.host_io_steps
-        hio = {"value": args.gops * n_mb * args.host_io_steps / dth, "unit": "MB/s", "ms_per_step": dth / args.host_io_steps * 1e3,
-               "h2d_bytes_per_frame": up / (len(encs) * args.host_io_steps), "d2h_bytes_per_frame": down / (len(encs) * args.host_io_steps),
-               "note": "source frames host->device from pinned memory + records and embedding vectors device->host through the C ABI, serialised with the compute (no overlap)"}
     if prof is not None:
         pcamv_amd.load_library().pcamv_gpu_prof_fetch(prof, 0)
-        nmb = args.gops * n_mb * args.steps
+        nmb = G * n_mb * args.steps
         names = ["pop+wait", "search", "publish", "reconstruct+RCA", "whole iteration", "-", "16x16 (+skip probe)", "8x8", "sub8x8 + 16x8 + 8x16",
                  "final qpel refine", "reconstruction", "neighbour load", "record store",
                  "pop: ticket (or pass 2: pop+wait)", "pop: queue entry wait (or pass 2: work)", "pop: descriptor load (or pass 2: publish)",
                  "rd: intra SATD analysis", "rd: x264_mb_analyse_p_rd", "rd trial: predict + transform", "rd trial: ssd + psy", "rd trial: cabac header",
                  "rd trial: cabac residual", "rd: final encode + entropy commit", "-",
                  "residual: per-block data", "residual: coded_block_flag chains", "residual: maps + levels", "COUNT residual walks", "COUNT blocks with levels",
-                 "COUNT coded blocks", "COUNT non-zero levels", "-"]
+                 "COUNT coded blocks", "COUNT non-zero levels", "-",
+                 "COUNT list evaluations", "COUNT candidates", "-", "-", "-", "-", "list evaluation (cycles)"]
         print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
-    # dominant kernel: average duration of one launch, HIP events on its own stream
-    dom = batch.dominant_kernel()
-    avg_ms, n_launch = batch.kernel_time(reset=False)
-    n_diag = (W // 16) + 2 * (H // 16 - 1)
-    mbs, emb = encs[0].fetch_results(want_embed=True)
-    ber = None
-    if emb["stc_ok"] == 1 and emb["m"] >= 10:
-        final = encs[0].final_mvs(mbs)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from helpers import carrier_lsbs
-        try:
-            ext = pcamv_amd.stc_extract(carrier_lsbs(final), emb["m"])
-            ber = float((ext != emb["message"]).mean())
-        except pcamv_amd.PcamvError:        # sub-matrix widths outside 2..20: the columns come from the embedder's LCG history,
-            ber = None                       # which the stand-alone extractor does not have (payloads below 1/20 bit per MV)
-    summary = torch.tensor([emb["n"], emb["m"], emb["num_flip"]], device=cdev, dtype=torch.int64)
-    if dist is not None:
-        gathered = [torch.zeros_like(summary) for _ in range(world)]
-        dist.all_gather(gathered, summary)      # per-GOP result summary to every rank over RCCL (not timed)
 
-    units = args.gops * n_mb * args.steps * world
+    # dominant kernel: average duration of one launch, HIP events on its own stream, over the timed steps
+    dom = run.batch.dominant_kernel()
+    avg_ms, n_launch = run.batch.kernel_time(reset=False)
+    n_diag = (W // 16) + 2 * (H // 16 - 1)
+    flow = dom.startswith("k_analyse_flow")
+
+    # the embedded payload comes back out of the final motion vectors (first GOP of this rank)
+    mbs, emb = run.encs[0].fetch_results(want_embed=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import carrier_lsbs
+    ber = None
+    if emb["m"] > 0:
+        if emb["stc_ok"] != 1:
+            sys.exit("bench.py: the syndrome-trellis embedding of GOP 0 failed")
+        final = run.encs[0].final_mvs(mbs)
+        ext = pcamv_amd.stc_extract(carrier_lsbs(final), emb["m"])
+        ber = float((ext != emb["message"]).mean())
+
+    # N > 1: per-rank summary to every rank, and (--strong) the payloads of the set's first GOPs to rank 0 in GOP order;
+    # tensor collectives over RCCL, after the timed region
+    summary = torch.tensor([emb["n"], emb["m"], emb["num_flip"]], device=cdev, dtype=torch.int64)
+    gathered = None
+    if dist is not None:
+        allsum = [torch.zeros_like(summary) for _ in range(world)]
+        dist.all_gather(allsum, summary)
+    if args.strong:
+        n_gather = min(args.gops, 64)
+        local_payload = {}
+        for k, g in enumerate(gop_assignment(n_gather, world, rank)):       # rank r's k-th GOP is r + k * world
+            m_k, e_k = run.encs[k].fetch_results(want_embed=True)
+            local_payload[g] = pack_gop_payload(m_k, np.asarray(e_k["flip"])[:e_k["n"]])
+        out_p = gather_payloads(dist, local_payload, n_gather, world, rank, device=cdev)
+        if rank == 0:
+            h = hashlib.sha1()
+            for b in out_p:
+                h.update(b)
+            gathered = {"gops": n_gather, "bytes": sum(len(b) for b in out_p), "sha1": h.hexdigest(),
+                        "note": "records + flip map of the last step of the set's first GOPs, in GOP order (all_gather of sizes + gather of padded "
+                                "bytes over RCCL); with the same --gops/--steps the hash does not depend on the number of ranks"}
+
+    units = total_gops * n_mb * args.steps
     value = units / dt
-    B_SEARCH = 1920.0       # algorithmic bytes per MB of one analysis/encode pass
-    # k_analyse_flow: one launch = the whole analysis pass of every GOP in flight;
-    # k_search_diag:  one launch = one anti-diagonal of every GOP in flight
-    mbs_per_launch = args.gops * n_mb / (1 if dom == "k_analyse_flow" else n_diag)
+    # one launch of the flow kernels = the analysis pass of every GOP of the rank; of k_search_diag = one anti-diagonal of them
+    mbs_per_launch = G * n_mb / (1 if flow else n_diag)
     achieved = B_SEARCH * mbs_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM-side traffic of the dominant kernel: PMC FETCH_SIZE + WRITE_SIZE of this same command, collected in
-    # separate rocprofv3 passes (tools/dbg/pmc_traffic.sh) and committed under profiles/; scaled to one launch
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if dom == "k_analyse_flow" and os.path.exists(tfile):
+    # HBM-side traffic and SIMD issue counters of the dominant kernel: from the committed PMC summaries of this same command
+    # (tools/dbg/pmc.sh + pmc_profiles.py; separate rocprofv3 passes), not measured in this run -- labelled with their source
+    traffic, traffic_src, issue = None, None, None
+    tag = "rd" if dom == "k_analyse_flow_rd" else "base"
+    tfile = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{tag}.json")
+    if os.path.exists(tfile):
         with open(tfile) as fh:
-            tj = json.load(fh)["k_analyse_flow_bytes_per_mb"]
-        traffic = (tj["fetch_raw"] + tj["write"]) * mbs_per_launch
-    # what actually bounds the kernel (committed SQ counter summary of the same command): share of the SIMDs' issue
-    # slots in use = waves/SIMD x ACTIVE_INST_ANY / WAVE_CYCLES; the VALU alone = waves/SIMD x ACTIVE_INST_VALU / WAVE_CYCLES
-    issue = None
-    sfile = os.path.join(ROOT, "profiles", "r01_pmc_sq_summary.json")
-    if dom == "k_analyse_flow" and os.path.exists(sfile):
+            tj = json.load(fh)
+        traffic = tj["bytes_per_mb"] * mbs_per_launch
+        traffic_src = f"profiles/r02_pmc_traffic_{tag}.json ({tj['gops']} GOPs in flight; {tj['bytes_per_mb']:.0f} B per macroblock scaled to this launch)"
+    sfile = os.path.join(ROOT, "profiles", f"r02_pmc_sq_summary_{tag}.json")
+    if os.path.exists(sfile):
         with open(sfile) as fh:
-            sq = json.load(fh)["k_analyse_flow_totals"]
-        issue = {"waves_per_simd": 4, "issue_slots_used": 4 * sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
-                 "valu_busy": 4 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "wave_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                 "source": "profiles/r01_pmc_sq_summary.json"}
+            issue = dict(json.load(fh)["summary"], source=f"profiles/r02_pmc_sq_summary_{tag}.json (committed profile of this command, not this run)")
     out = {
         "metric": "1080p macroblocks/s (embed on)", "value": value, "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} synthetic I420, --me {args.me} --subme {args.subme} --qp {args.qp} "
-                               f"--emrate {args.emrate}, {args.gops} closed GOPs in flight per GPU, " + ("closed loop (pass 2 + loop filter on the GPU)" if args.closed_loop else "open-loop reference"),
-                   "mb_per_frame": n_mb, "frames_per_step_per_gpu": args.gops,
-                   "note": "BASELINE config 3 asks --subme 7; subme>=6 needs CABAC-size RDO (SURVEY 8f rank 3), not on the GPU path yet"},
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: {W}x{H} synthetic I420, --me {args.me} --subme {args.subme} --qp {args.qp} --emrate {args.emrate}"
+                               f"{' --no-cabac' if args.no_cabac else ''}, " + ("closed loop (pass 2 + loop filter on the GPU)" if closed_loop else "open-loop reference")
+                               + (f", {args.gops} closed GOPs in total sharded over the ranks" if args.strong else f", {args.gops} closed GOPs in flight per GPU"),
+                   "mb_per_frame": n_mb, "gops_per_gpu": G, "frames_per_step": total_gops,
+                   "value_is": "inputs resident in HBM when the timed region starts; pcie_inclusive is the host-fed pipeline"},
         "extracted_payload_BER": ber,
         "carriers_per_frame": int(emb["n"]), "bits_per_frame": int(emb["m"]),
-        # 2 x (1920 + 1024) B per macroblock with both passes, 1920 + 1024 for the first pass alone
-        "hbm_algorithmic_GBps_whole_path": (5888.0 if args.closed_loop else 2944.0) * value / 1e9,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": traffic,
-                     "avg_launch_ms": avg_ms, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH,
-                     "issue_bound": issue},
+        "hbm_algorithmic_GBps_whole_path": (B_WHOLE if closed_loop else B_WHOLE / 2) * value / 1e9,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "avg_launch_ms": avg_ms, "launches_timed": n_launch, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH,
+                     "bound_note": "byte/integer work priced against HBM as the contract asks; what limits this kernel is not bandwidth but the "
+                                   "dependent chain inside a macroblock (a wave is parked on s_waitcnt most of its time): issue_counters, DESIGN.md",
+                     "issue_counters": issue},
     }
+    if gathered is not None:
+        out["gathered_payloads"] = gathered
 
-    if hio is not None:
-        out["pcie_inclusive"] = hio
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
+    solo = rank == 0 and world == 1
+    # ---- PCIe-inclusive pipeline (extra): every step's source pictures go host -> device and its records + flip maps device -> host,
+    # double-buffered and overlapped with the compute: uploads of step k+1 and downloads of step k run on a copy stream during the compute
+    if solo and args.host_io_steps > 0:
+        mb_bytes, flip_bytes = n_mb * MB_RECORD, 16 * n_mb
+        row_out = mb_bytes + flip_bytes
+        fbytes = [pl.numel() for pl in dframes[0]]
+        row_in = sum(fbytes)
+        offs = [0, fbytes[0], fbytes[0] + fbytes[1]]
+        hsrc = [torch.cat([pl.reshape(-1) for pl in fr]).cpu().pin_memory() for fr in dframes]          # pinned source pictures (Y|U|V per frame)
+        dstage = [torch.empty((G, row_in), dtype=torch.uint8, device=dev) for _ in range(2)]            # device staging of the uploads, two steps deep
+        d_out = torch.empty((G, row_out), dtype=torch.uint8, device=dev)                                 # device staging of the results
+        h_out = torch.empty((G, row_out), dtype=torch.uint8).pin_memory()
+        copy_st = torch.cuda.Stream(device=dev)
+        up_done = [torch.cuda.Event() for _ in range(2)]
+        step_done = [torch.cuda.Event() for _ in range(2)]
+        down_done = torch.cuda.Event()
+
+        def upload(t, buf):
+            with torch.cuda.stream(copy_st):
+                for k in range(G):
+                    dstage[buf][k].copy_(hsrc[(t + run.phases[k] + 1) % nfr], non_blocking=True)
+                up_done[buf].record(copy_st)
+
+        def fenc_of(buf):
+            base = dstage[buf].data_ptr()
+            return lambda k: [base + k * row_in + o for o in offs]
+
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        upload(t_next, 0)
+        for k in range(args.host_io_steps):
+            cur = k & 1
+            stream.wait_event(up_done[cur])
+            run.step(t_next + k, args.qp, args.emrate, stream.cuda_stream, fenc_of(cur))
+            if k > 0:
+                stream.wait_event(down_done)           # the result staging is free again
+            run.batch.copy_results_async(d_out.data_ptr(), row_out, d_out.data_ptr() + mb_bytes, row_out, stream.cuda_stream)
+            step_done[cur].record(stream)
+            if k + 1 < args.host_io_steps:             # the next step's pictures up (its staging was last read by step k-1)
+                if k > 0:
+                    copy_st.wait_event(step_done[cur ^ 1])
+                upload(t_next + k + 1, cur ^ 1)
+            with torch.cuda.stream(copy_st):           # this step's results down as soon as it is done (overlaps the next step)
+                copy_st.wait_event(step_done[cur])
+                h_out.copy_(d_out, non_blocking=True)
+                down_done.record(copy_st)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        t_next += args.host_io_steps
+        got = np.frombuffer(h_out[0, :mb_bytes].numpy().tobytes(), dtype=np.uint8)
+        chk = np.asarray(run.encs[0].fetch_results(want_embed=False)[0]).view(np.uint8).reshape(-1)
+        if not np.array_equal(got, chk):
+            sys.exit("bench.py: the records downloaded by the overlapped pipeline differ from the blocking fetch")
+        out["pcie_inclusive"] = {"value": G * n_mb * args.host_io_steps / dth, "unit": "MB/s", "ms_per_step": dth / args.host_io_steps * 1e3,
+                                 "steps": args.host_io_steps, "h2d_bytes_per_frame": row_in, "d2h_bytes_per_frame": row_out,
+                                 "note": "extra, never `value`: source pictures host->device from pinned memory and records + flip maps device->host "
+                                         "(pcamv_gpu_batch_copy_results_async) on a copy stream, double-buffered, overlapped with the compute; "
+                                         "the pipeline's fill and drain are inside the timed region"}
+        del dstage, d_out, h_out, hsrc
+
+    # ---- throughput against the number of GOPs in flight (extra): a frame's macroblocks form one chain, so few GOPs = few busy waves
+    if solo and args.g_sweep:
+        sweep = []
+        for g_n in [int(x) for x in args.g_sweep.split(",") if x]:
+            if g_n >= G:
+                continue
+            sub = Gops(pcamv_amd, p, dframes, range(g_n), local, closed_loop)
+            sub.step(0, args.qp, args.emrate, stream.cuda_stream)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for t in range(2):
+                sub.step(1 + t, args.qp, args.emrate, stream.cuda_stream)
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - ts) / 2
+            sweep.append({"gops": g_n, "value": g_n * n_mb / d, "unit": "MB/s", "ms_per_step": d * 1e3})
+            sub.close()
+        sweep.append({"gops": G, "value": value, "unit": "MB/s", "ms_per_step": dt / args.steps * 1e3})
+        out["g_sweep"] = sweep
+
+    # ---- CPU baseline (rank 0, N=1): the port on a bounded sample of the same 1080p workload; the reference itself on CIF
+    if solo and args.cpu_frames > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
-        op = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac)
-        assert (op.i_psy_rd, op.i_chroma_qp_offset) == (p.i_psy_rd, p.i_chroma_qp_offset)
-        o = orc.Oracle(op)
-        tcpu = 0.0
-        prev = (None, None)
-        ref = clip[0]
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import helpers
-        for t in range(args.cpu_frames):
-            if not args.closed_loop:
-                ref = clip[t % nfr]
-            o.set_fenc(*clip[(t + 1) % nfr])
-            c0 = time.perf_counter()
-            o.set_ref(*ref, *prev)                      # plane production is part of the path
-            m_o, _ = o.analyse_pframe(args.qp, 1)
-            e_o = o.embed_pframe(m_o, args.emrate)
-            if args.closed_loop:                        # second pass: final MVs, reconstruction, loop filter
-                fo, _, _, ref, _ = o.pass2_pframe(args.qp, m_o, (np.asarray(e_o["flip"]) == 1).astype(np.uint8))
-            tcpu += time.perf_counter() - c0
-            if args.closed_loop:
-                prev = helpers.mv_field(fo["mv"], W // 16, H // 16)
-        o.close()
-        out["cpu_baseline"] = {"value": args.cpu_frames * n_mb / tcpu, "unit": "MB/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_frames} P frames of the same {W}x{H} workload ({'both passes' if args.closed_loop else 'first pass only'}), oracle/pcamv_oracle.c (scalar C, 1 thread)"}
+
+        def port_run(w, h, frames, clip_, mv_range):
+            o = orc.Oracle(orc.make_params(w, h, me=args.me, subme=args.subme, mv_range=mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac))
+            tcpu, prev, ref = 0.0, (None, None), clip_[0]
+            for t in range(frames):
+                if not closed_loop:
+                    ref = clip_[t % len(clip_)]
+                o.set_fenc(*clip_[(t + 1) % len(clip_)])
+                c0 = time.perf_counter()
+                o.set_ref(*ref, *prev)                      # plane production is part of the path
+                m_o, _ = o.analyse_pframe(args.qp, 1)
+                e_o = o.embed_pframe(m_o, args.emrate)
+                if closed_loop:                             # second pass: final MVs, reconstruction, loop filter
+                    fo, _, _, ref, _ = o.pass2_pframe(args.qp, m_o, (np.asarray(e_o["flip"]) == 1).astype(np.uint8))
+                tcpu += time.perf_counter() - c0
+                if closed_loop:
+                    prev = helpers.mv_field(fo["mv"], w // 16, h // 16)
+            o.close()
+            return tcpu
+
+        op0 = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac)
+        assert (op0.i_psy_rd, op0.i_chroma_qp_offset) == (p.i_psy_rd, p.i_chroma_qp_offset)
+        tcpu = port_run(W, H, args.cpu_frames, clip, p.i_mv_range)
+        cb = {"value": args.cpu_frames * n_mb / tcpu, "unit": "MB/s", "cores": 1, "kind": "port",
+              "sample": f"{args.cpu_frames} P frames of the same {W}x{H} workload ({'both passes' if closed_loop else 'first pass only'}, embedding on), "
+                        f"oracle/pcamv_oracle.c (scalar C, 1 thread), {tcpu:.1f} s"}
+        # The reference's own code (oracle/_ref, built from its sources) keeps its per-frame record in arrays sized for CIF, so it is
+        # timed on CIF: analysis + second pass with the same options (its STC call is outside the harness: the flip map comes from the
+        # port, untimed); the port on the same frames gives the ratio between the two.
+        import refh
+        if refh.available() and args.cpu_cif_frames > 0:
+            cw, ch, cn = 352, 288, 396
+            cclip = make_clip(cw, ch, nfr, seed=13)
+            mvr = pcamv_amd.level_mv_range(cw, ch)
+            r = refh.Ref(cw, ch, qp=args.qp, me=args.me, subme=args.subme, mv_range=mvr, cabac=int(p.b_cabac), embed=1, inter_flags=int(p.inter))
+            oe = orc.Oracle(orc.make_params(cw, ch, me=args.me, subme=args.subme, mv_range=mvr, tscale=256, inter=p.inter, cabac=p.b_cabac))
+            tref, prev, ref = 0.0, (None, None), cclip[0]
+            for t in range(args.cpu_cif_frames):
+                if not closed_loop:
+                    ref = cclip[t % nfr]
+                r.set_fenc(*cclip[(t + 1) % nfr])
+                c0 = time.perf_counter()
+                r.set_ref(*ref, *prev)
+                m_r, _ = r.analyse_pframe(args.qp)
+                tref += time.perf_counter() - c0
+                if closed_loop:
+                    e_r = oe.embed_pframe(m_r.view(orc.MB_DTYPE), args.emrate)
+                    flips = (np.asarray(e_r["flip"]) == 1).astype(np.int8)
+                    c0 = time.perf_counter()
+                    fm, _, _, ref, _ = r.pass2_pframe(flips, args.qp)
+                    tref += time.perf_counter() - c0
+                    prev = helpers.mv_field(fm["mv"], cw // 16, ch // 16)
+            oe.close()
+            tport = port_run(cw, ch, args.cpu_cif_frames, cclip, mvr)
+            cb["ref_cif"] = {"value": args.cpu_cif_frames * cn / tref, "unit": "MB/s", "cores": 1, "kind": "reference",
+                             "port_on_same_sample": args.cpu_cif_frames * cn / tport,
+                             "sample": f"{args.cpu_cif_frames} CIF P frames, same options, through oracle/_ref (the reference's sources, gcc -O3): analysis"
+                                       f"{' + second pass' if closed_loop else ''} ({tref:.1f} s); the port's figure beside it also contains its embedding ({tport:.1f} s)"}
+        out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out))
-    batch.close()
-    for enc in encs:
-        enc.close()
+    run.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -158,8 +158,15 @@ int pcamv_gpu_final_mvs(pcamv_ctx_t *ctx, pcamv_mb_t *out_mb);
 int pcamv_gpu_pass2_pframe(pcamv_ctx_t *ctx, const uint8_t *flips, int n_flips, pcamv_mb_t *out_final,
                            uint8_t *const recon[3], uint8_t *const deblocked[3]);
 
-/* Syndrome-trellis extraction (host side of the BER check): stego bits -> message bits. */
+/* Syndrome-trellis extraction (host side of the BER check): stego bits -> message bits (stc_extract, embed.h:340-393).
+ * Sub-matrix widths 2..20 come from the code's tables; outside that range (payloads below 1/20 bit per MV, or 1 bit per MV) the
+ * reference draws the columns from a process-wide LCG (embed.h:134-139) that every such frame advances, so the extractor needs
+ * the generator's state: *lcg = state before this frame's embedding (1 for the first P frame of a process -- of a closed GOP
+ * under the per-GOP parity definition; a context starts there), updated to the state after it, to be carried to the next frame
+ * exactly as the reference's own extractor process carries it.  pcamv_gpu_stc_extract = the same with lcg == NULL: tabulated
+ * widths only, PCAMV_EUNSUP otherwise. */
 int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int matrixheight, uint8_t *message);
+int pcamv_gpu_stc_extract_lcg(const uint8_t *stego, int n, int m, int matrixheight, int64_t *lcg, uint8_t *message);
 
 /* Device-resident variants used by bench.py and the multi-frame pipeline: planes are raw
  * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */
@@ -198,8 +205,15 @@ int  pcamv_gpu_batch_set_closed_loop(pcamv_batch_t *batch, int on);
 int  pcamv_gpu_recon_device(pcamv_ctx_t *ctx, void *planes[3]);
 /* host copy of those planes (tightly packed w*h, w/2*h/2 x2) after synchronising */
 int  pcamv_gpu_fetch_recon(pcamv_ctx_t *ctx, uint8_t *const planes[3]);
-/* name of the analysis kernel the batch's schedule launches ("k_analyse_flow" or "k_search_diag") */
+/* name of the analysis kernel the batch's schedule launches ("k_analyse_flow", "k_analyse_flow_rd" with --subme >= 6,
+ * "k_analyse_flow_tesa", or "k_search_diag") */
 const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *batch);
+/* Results of the step enqueued last, for every context of the batch, copied on `stream` without synchronising the host:
+ * context i's pass-1 records (n_mb x pcamv_mb_t) to (char *)dst_mb + i * mb_stride and, when dst_flip != NULL, its flip map
+ * (16 * n_mb bytes, the first `n carriers` meaningful) to (char *)dst_flip + i * flip_stride.  The destinations may be device
+ * memory or pinned host memory; the caller orders `stream` after the step's stream (an event) and owns the synchronisation.
+ * This is what lets a host pipeline overlap a step's downloads with the next step (bench.py pcie_inclusive). */
+int  pcamv_gpu_batch_copy_results_async(pcamv_batch_t *batch, void *dst_mb, size_t mb_stride, void *dst_flip, size_t flip_stride, void *stream);
 
 /* Average duration in ms of the dominant kernel over the launches since the last reset,
  * measured with hipEvents on the launch stream (bench.py roofline). */

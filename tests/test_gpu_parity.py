@@ -500,28 +500,31 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     enc.close(); o.close(); o2.close()
 
 
-@pytest.mark.parametrize("n_gops", [2, 16])
-def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
-    """GOPs advanced together through two closed-loop steps (dataflow analysis, embedding, then pass 2 + loop
-    filter through the same dataflow queue; the second step's reference is the first step's deblocked picture
-    and final motion field, both taken from the device): records, embedding and deblocked pictures vs the oracle.
-    16 GOPs = one queue per XCD, hand-offs inside and across XCDs (2 GOPs share a single queue)."""
+def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate=0.5, statics=(0, 64, 128), noise=6):
+    """GOPs advanced together through closed-loop steps (dataflow analysis, embedding, then pass 2 + loop filter through the same
+    dataflow queue; every later step's reference is the step's own deblocked picture and final motion field, both taken from the
+    device): records, embedding vectors, deblocked pictures vs the oracle, and the payload back out of the final motion vectors
+    (the extractor carries the STC column generator's state from frame to frame, one process per GOP)."""
     import torch
     import orc
     from pcamv_amd.synth import make_clip
-    W, H, qp = 352, 288, 30
-    clips = [make_clip(W, H, 3, seed=61 + g, static_cols=64 * (g % 3)) for g in range(n_gops)]
+    clips = [make_clip(W, H, steps + 1, seed=seed0 + g, static_cols=statics[g % len(statics)], noise=noise) for g in range(n_gops)]
     dev = torch.device("cuda", 0)
     d = [[[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip] for clip in clips]
     mvr = pc.level_mv_range(W, H)
-    p = _params(pc, W, H, pc.ME_NAMES["hex"], 5, 0x10, mvr)
+    rd = subme >= 6
+    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=0x11 if rd else 0x10)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset) if rd \
+        else _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr)
     encs = [pc.Encoder(p) for _ in range(n_gops)]
     batch = pc.Batch(encs)
     batch.set_closed_loop(True)
-    oracles = [orc.Oracle(orc.make_params(W, H, me="hex", subme=5, mv_range=mvr)) for _ in range(n_gops)]
+    oracles = [orc.Oracle(op) for _ in range(n_gops)]
+    lcgs = [pc.StcLcg(1) for _ in range(n_gops)]
     refs = [clips[g][0] for g in range(n_gops)]
     prevs = [(None, None)] * n_gops
-    for t in (1, 2):
+    bits = 0
+    for t in range(1, steps + 1):
         for g, enc in enumerate(encs):
             if t == 1:      # (the internal field of a fresh context holds no motion: same as no previous frame)
                 enc.set_ref_device(d[g][0][0].data_ptr(), d[g][0][1].data_ptr(), d[g][0][2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
@@ -529,7 +532,7 @@ def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
                 r = enc.recon_device()
                 enc.set_ref_device(r[0], r[1], r[2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
             enc.set_fenc_device(d[g][t][0].data_ptr(), d[g][t][1].data_ptr(), d[g][t][2].data_ptr())
-        batch.step(qp, 0.5, 0)
+        batch.step(qp, emrate, 0)
         for g, enc in enumerate(encs):
             o = oracles[g]
             mbs, emb = enc.fetch_results(want_embed=True)
@@ -537,12 +540,19 @@ def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
             mbs_o, _ = o.analyse_pframe(qp, 1)
             for f in mbs.dtype.names:
                 assert np.array_equal(mbs[f], mbs_o[f]), f"step {t} GOP {g}: {f}"
-            emb_o = o.embed_pframe(mbs_o, 0.5)
-            assert np.array_equal(emb["flip"], emb_o["flip"]), f"step {t} GOP {g}: flips"
+            emb_o = o.embed_pframe(mbs_o, emrate)
+            assert (emb["n"], emb["m"], emb["stc_ok"], emb["num_flip"]) == (emb_o["n"], emb_o["m"], emb_o["stc_ok"], emb_o["num_flip"])
+            for k in ("cover", "rho", "message", "stego", "flip"):
+                assert np.array_equal(emb[k], emb_o[k]), f"step {t} GOP {g}: {k}"
             fo, _, _, dbk_o, _ = o.pass2_pframe(qp, mbs_o, (np.asarray(emb_o["flip"]) == 1).astype(np.uint8))
             dbk = enc.fetch_recon()
             for a, b, nm in zip(dbk, dbk_o, "yuv"):
                 assert np.array_equal(a, b), f"step {t} GOP {g}: deblocked {nm}"
+            if emb["m"] > 0:
+                assert emb["stc_ok"] == 1
+                final = enc.final_mvs(mbs)
+                assert np.array_equal(pc.stc_extract(helpers.carrier_lsbs(final), emb["m"], lcg=lcgs[g]), emb["message"]), f"step {t} GOP {g}: BER != 0"
+                bits += emb["m"]
             refs[g] = dbk_o
             prevs[g] = helpers.mv_field(fo["mv"], W // 16, H // 16)
     batch.close()
@@ -550,3 +560,42 @@ def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
         enc.close()
     for o in oracles:
         o.close()
+    return bits
+
+
+@pytest.mark.parametrize("n_gops", [2, 16])
+def test_closed_loop_batch_step_matches_oracle(pc, n_gops):
+    """16 GOPs = one queue per XCD, hand-offs inside and across XCDs (2 GOPs share a single queue)."""
+    assert _closed_loop_vs_oracle(pc, 352, 288, "hex", 5, 30, n_gops, 2, 61) > 0
+
+
+# BASELINE.json's configurations at their own sizes and options (synthetic clips of the SURVEY 8(d) generator), closed loop,
+# embedding on, payload extracted again
+def test_config1_cif_dia_35_bits_per_frame(pc):
+    """config 1: CIF, --me dia, the reference's default --subme (6), "1 kbit" = --emrate 35 (bits per P frame): few bits over many
+    carriers = sub-matrix widths beyond the tables, columns from the LCG, which the extractor follows over the frames"""
+    assert _closed_loop_vs_oracle(pc, 352, 288, "dia", 6, 26, 1, 4, 7, emrate=35.0, statics=(0,), noise=10) == 4 * 35
+
+
+def test_config2_720p_hex(pc):
+    assert _closed_loop_vs_oracle(pc, 1280, 720, "hex", 6, 26, 1, 2, 11, statics=(320,)) > 1000
+
+
+def test_config3_1080p_umh_subme7_closed_loop(pc):
+    """config 3 as written (the bench workload): two GOPs, two chained steps"""
+    assert _closed_loop_vs_oracle(pc, 1920, 1088, "umh", 7, 26, 2, 2, 13, statics=(480, 0)) > 4000
+
+
+def test_config5_2160p_esa(pc):
+    """config 5: 3840x2160, exhaustive search, one GOP, one full P frame (32400 macroblocks in one chain)"""
+    assert _closed_loop_vs_oracle(pc, 3840, 2160, "esa", 6, 26, 1, 1, 17, statics=(1920,)) > 4000
+
+
+def test_rd_instances_agree(pc, monkeypatch):
+    """the RD instance has two builds (pcamv_rd.hip): small batches run the one with every register (1 wave per SIMD), large
+    ones the one with 4 waves per SIMD; here the second is forced onto a small batch: CABAC (one chain per frame), then the
+    CAVLC sizes (wavefront order) through the fixture-style sweep"""
+    monkeypatch.setenv("PCAMV_RD_INSTANCE", "hi")
+    assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 3, 2, 71) > 0
+    test_rd_mode_decision_matches_oracle(pc, RD_SWEEP[1])
+    test_rd_mode_decision_matches_oracle(pc, RD_SWEEP[6])

@@ -68,6 +68,9 @@ PASS2 = [
     (320, 240, "hex", 5, 18, 9, 96, 0.25),      # fine quantiser: many non-zero blocks, strong bS = 2 edges
     (352, 288, "hex", 5, 38, 5, 0, 0.4),        # moving skips next to flipped MVs: skip MVs re-predicted in pass 2
     (352, 288, "hex", 5, 42, 6, 0, 0.4),
+    # the RD levels: psy-RD's chroma QP offset (-2) reaches the second pass' chroma quantiser
+    (352, 288, "umh", 7, 26, 6, 96, 0.4),
+    (176, 144, "hex", 6, 32, 5, 0, 0.3),
 ]
 
 

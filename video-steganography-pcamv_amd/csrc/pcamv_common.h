@@ -254,7 +254,8 @@ struct MEState {
 
 /* diagnostics build (-DPCAMV_PROF): wave cycles per phase of k_analyse_flow, summed in pcamv_prof[] (tools/dbg/prof_phases.py) */
 #if defined(PCAMV_PROF) && !defined(PCAMV_HOST_EMU)
-static __device__ unsigned long long pcamv_prof[32];
+#define PCAMV_PROF_N 48
+static __device__ unsigned long long pcamv_prof[PCAMV_PROF_N];
 #define PROF_T() __builtin_readcyclecounter()
 #define PROF_ADD(i, t0) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(PROF_T() - (t0))); } while (0)
 #define PROF_CNT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&pcamv_prof[i], (unsigned long long)(n)); } while (0)

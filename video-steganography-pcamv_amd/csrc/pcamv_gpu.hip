@@ -32,7 +32,7 @@ struct pcamv_batch {
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
-    int sched_flow, flow_waves, flow2_waves, closed_loop;
+    int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo;
     unsigned *d_flow;
     FlowDev fl, fl2;          /* queue descriptors of the analysis and of the second pass */
     char err[256];
@@ -80,13 +80,16 @@ static int bfail(pcamv_batch *b, int code, const char *fmt, ...)
 extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 #ifdef PCAMV_PROF
 int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
+int pcamv_rd_prof_fetch_lo(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
-    unsigned long long rd[32];
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    unsigned long long rd[PCAMV_PROF_N];
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * PCAMV_PROF_N) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[PCAMV_PROF_N] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
     if (pcamv_rd_prof_fetch(rd, reset)) return -1;
-    for (int i = 0; i < 32; i++) out[i] += rd[i];
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
+    if (pcamv_rd_prof_fetch_lo(rd, reset)) return -1;
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     return 0;
 }
 #endif
@@ -181,8 +184,14 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         b->fl.raster = F.b_mbrd && F.b_cabac;
         int per_cu = 0, n_cu = 0;
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow, 64, 0);
-        if (e == hipSuccess && F.b_mbrd) { per_cu = pcamv_flow_rd_waves_per_cu(); if (per_cu < 0) e = hipErrorUnknown; }
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device);
+        if (e == hipSuccess && F.b_mbrd) {
+            /* which build of the RD instance (pcamv_rd.hip): one wave per SIMD while the chains fit that anyway */
+            const char *inst = getenv("PCAMV_RD_INSTANCE");
+            b->rd_lo = inst ? !strcmp(inst, "lo") : (b->fl.raster && n <= 4 * n_cu);
+            per_cu = b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
+            if (per_cu < 0) e = hipErrorUnknown;
+        }
         const char *wv = getenv("PCAMV_FLOW_WAVES");
         long waves = wv ? atol(wv) : (long)per_cu * n_cu;
         if (waves < 1) waves = 1;
@@ -233,7 +242,28 @@ extern "C" int pcamv_gpu_recon_device(pcamv_ctx_t *c, void *planes[3])
     for (int i = 0; i < 3; i++) planes[i] = c->d_rec[i];
     return 0;
 }
-extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) { return b && b->sched_flow ? "k_analyse_flow" : "k_search_diag"; }
+static const char *dominant_kernel(const pcamv_batch *b)
+{
+    if (!b || !b->sched_flow) return "k_search_diag";
+    if (b->n > 0 && b->ctx[0]->F.b_mbrd) return "k_analyse_flow_rd";
+    for (int i = 0; i < b->n; i++) if (b->ctx[i]->F.me_method == PCAMV_ME_TESA) return "k_analyse_flow_tesa";
+    return "k_analyse_flow";
+}
+extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) { return dominant_kernel(b); }
+extern "C" int pcamv_gpu_batch_copy_results_async(pcamv_batch_t *b, void *dst_mb, size_t mb_stride, void *dst_flip, size_t flip_stride, void *stream)
+{
+    if (!b || !dst_mb) return PCAMV_EINVAL;
+    HIPCHKB(b, hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < b->n; i++) {
+        pcamv_ctx *c = b->ctx[i];
+        const size_t nb = (size_t)c->F.n_mb * sizeof(pcamv_mb_t);
+        if (mb_stride < nb || (dst_flip && flip_stride < (size_t)c->cap)) return PCAMV_EINVAL;
+        HIPCHKB(b, hipMemcpyAsync((char *)dst_mb + (size_t)i * mb_stride, c->d_rec_mb, nb, hipMemcpyDefault, st));
+        if (dst_flip) HIPCHKB(b, hipMemcpyAsync((char *)dst_flip + (size_t)i * flip_stride, c->d_flip, (size_t)c->cap, hipMemcpyDefault, st));
+    }
+    return 0;
+}
 
 /* ------------------------------------------------------------------ contexts */
 extern "C" void pcamv_gpu_close(pcamv_ctx_t *c);
@@ -464,7 +494,7 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         if (b->sched_flow) {
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-            if (F.b_mbrd) pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl);
+            if (F.b_mbrd) { if (b->rd_lo) pcamv_launch_flow_rd_lo((unsigned)b->flow_waves, st, dF, b->fl); else pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl); }
             else if (tesa) pcamv_launch_flow_tesa((unsigned)b->flow_waves, st, dF, b->fl);
             else hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }
@@ -750,12 +780,12 @@ static int batch_kernel_time(pcamv_batch *b, double *avg_ms, int *launches, int 
 }
 extern "C" int pcamv_gpu_batch_kernel_time(pcamv_batch_t *b, const char *kernel, double *avg_ms, int *launches, int reset)
 {
-    if (!b || !kernel || strcmp(kernel, b->sched_flow ? "k_analyse_flow" : "k_search_diag")) return PCAMV_EINVAL;
+    if (!b || !kernel || strcmp(kernel, dominant_kernel(b))) return PCAMV_EINVAL;
     return batch_kernel_time(b, avg_ms, launches, reset);
 }
 extern "C" int pcamv_gpu_kernel_time(pcamv_ctx_t *c, const char *kernel, double *avg_ms, int *launches, int reset)
 {
-    if (!c || !kernel || strcmp(kernel, c->self->sched_flow ? "k_analyse_flow" : "k_search_diag")) return PCAMV_EINVAL;
+    if (!c || !kernel || strcmp(kernel, dominant_kernel(c->self))) return PCAMV_EINVAL;
     return batch_kernel_time(c->self, avg_ms, launches, reset);
 }
 
@@ -845,14 +875,42 @@ extern "C" int pcamv_gpu_final_mvs(pcamv_ctx_t *c, pcamv_mb_t *mbs)
     return 0;
 }
 
-/* syndrome-trellis extractor: H*y over GF(2) with stc_embed's sub-matrix schedule (embed.h:340-393) */
-extern "C" int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int hgt, uint8_t *message)
+/* sub-matrix columns as the embedder gets them (embed.h:141-199): the published tables for widths 2..20, columns drawn from the
+ * code's own LCG (embed.h:134-139) outside that range */
+static int host_stc_matrix(int width, int height, unsigned *cols, long long *lcg)
+{
+    if (width >= 2 && width <= 20 && height >= 7 && height <= 12) {
+        for (int i = 0; i < width; i++) cols[i] = pcamv_stc_mats[(height - 7) * 400 + (width - 1) * 20 + i];
+        return 1;
+    }
+    if (!lcg || width < 1 || width > STC_MAXW || (1 << (height - 2)) < width) return 0;
+    unsigned mask = (1u << (height - 2)) - 1, bop = (1u << (height - 1)) + 1;
+    long hold = (long)*lcg;
+    for (int i = 0; i < width; i++) {
+        unsigned r = 0; int j;
+        for (j = -1; j < i;) {
+            hold = hold * 214013L + 2531011L;
+            r = (((unsigned)(hold >> 16) & 0x7fff & mask) << 1) + bop;
+            for (j = 0; j < i; j++) if (cols[j] == r) break;
+        }
+        cols[i] = r;
+    }
+    *lcg = hold;
+    return 1;
+}
+/* syndrome-trellis extractor: H*y over GF(2) with stc_embed's sub-matrix schedule (embed.h:340-393).  lcg: state of the
+ * column generator before this frame's embedding (in) / after it (out); NULL = only the tabulated widths */
+extern "C" int pcamv_gpu_stc_extract_lcg(const uint8_t *stego, int n, int m, int hgt, int64_t *lcg, uint8_t *message)
 {
     if (!stego || !message || n <= 0 || m <= 0 || m > n || hgt < 7 || hgt > 12) return PCAMV_EINVAL;
     double invalpha = (double)n / m;
     int shorter = (int)floor(invalpha), longer = (int)ceil(invalpha);
-    if (shorter < 2 || longer > 20) return PCAMV_EUNSUP;   /* LCG-generated columns depend on process history */
-    const unsigned *cs = &pcamv_stc_mats[(hgt - 7) * 400 + (shorter - 1) * 20], *cl = &pcamv_stc_mats[(hgt - 7) * 400 + (longer - 1) * 20];
+    if (longer > STC_MAXW) return PCAMV_EUNSUP;
+    unsigned *cs = (unsigned *)malloc(2 * (size_t)STC_MAXW * sizeof(unsigned)), *cl = cs + STC_MAXW;
+    if (!cs) return PCAMV_ENOMEM;
+    long long st = lcg ? (long long)*lcg : 0;
+    if (!host_stc_matrix(shorter, hgt, cs, lcg ? &st : NULL) || !host_stc_matrix(longer, hgt, cl, lcg ? &st : NULL)) { free(cs); return PCAMV_EUNSUP; }
+    if (lcg) *lcg = (int64_t)st;
     memset(message, 0, m);
     int worm = 0, index = 0;
     for (int i = 0; i < m; i++) {
@@ -864,5 +922,10 @@ extern "C" int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int hgt
             if (stego[index])
                 for (int b = 0; b < hgt && i + b < m; b++) message[i + b] ^= (cols[k] >> b) & 1;
     }
+    free(cs);
     return 0;
+}
+extern "C" int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int hgt, uint8_t *message)
+{
+    return pcamv_gpu_stc_extract_lcg(stego, n, m, hgt, NULL, message);
 }

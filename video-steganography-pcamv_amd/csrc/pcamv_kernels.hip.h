@@ -525,12 +525,9 @@ static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow_tesa
 void pcamv_launch_flow_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 /* ... and so does the instance with the RD mode decision of --subme 6 / 7 (csrc/pcamv_rd.hip) */
 #ifdef PCAMV_RD_TU
-/* register budget of this instance: with CABAC a frame is one chain of macroblocks, so a GPU runs one or two waves per SIMD at
- * most (one chain per GOP in flight + the RCA work they hand off) and what counts is the time of a macroblock, not the
- * occupancy: at the search kernel's 128 VGPRs this code spilled 192 registers to scratch (a memory round trip each for a
- * lone wave); 2 waves per SIMD = 256 VGPRs */
+/* register budget: PCAMV_RD_OCC waves per SIMD, set by the translation unit (pcamv_rd.hip: 4, pcamv_rd_lo.hip: 1) */
 #ifndef PCAMV_RD_OCC
-#define PCAMV_RD_OCC 2
+#define PCAMV_RD_OCC 4
 #endif
 static __global__ void __launch_bounds__(64, PCAMV_RD_OCC) k_analyse_flow_rd(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
@@ -541,6 +538,8 @@ static __global__ void __launch_bounds__(64, PCAMV_RD_OCC) k_analyse_flow_rd(con
 #endif
 void pcamv_launch_flow_rd(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu(void);
+void pcamv_launch_flow_rd_lo(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu_lo(void);
 
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the

@@ -236,6 +236,8 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
     const int satd = flags & EV_SATD;
     const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     PCAMV_WAVE_SYNC();
+    const unsigned long long t_ev = PROF_T();
+    PROF_CNT(32, 1); PROF_CNT(33, n);
     {
         const int slot = lane >> lgn, blk = lane & (nblk - 1);
         const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
@@ -340,6 +342,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
     EvalRes res;
     if (key == 0x7fffffff) { res.cost = PCAMV_COST_MAX; res.idx = -1; }
     else { res.cost = key >> 6; res.idx = key & 63; }
+    PROF_ADD(38, t_ev);
 #ifdef PCAMV_TRACE      /* diagnostics build only: log every candidate of one macroblock (pcamv_gpu_trace_mb) */
     if (F.trace && L->mb_xy == F.trace_mb && lane == 0)
         for (int c = 0; c < n; c++) {

@@ -6,17 +6,33 @@
  * A kernel of its own for the same reason as the --me tesa instance (pcamv_tesa.hip): compiled into the common instance its
  * code costs the search of --subme <= 5 registers (141 spilled VGPRs, 552 bytes of scratch per lane when it was), and in a
  * translation unit of its own so that the library's instances compile side by side.
+ *
+ * Two builds of it (this file, and pcamv_rd_lo.hip which includes it with PCAMV_RD_LO defined), differing in the register
+ * budget only.  With CABAC a frame is ONE chain of macroblocks (the context states), so a batch of G GOPs keeps G waves busy
+ * (+ the RCA work they hand off):
+ *   - "lo", 1 wave per SIMD, up to 512 VGPRs, nothing spilled: the fastest macroblock.  Used while the chains fit the
+ *     1024 SIMDs anyway (G <= 4 x CUs): G=64 1215 ms per 1080p step, G=1024 1485 ms = 5.6 M MB/s;
+ *   - "hi", 4 waves per SIMD at 128 VGPRs (192 spilled): a wave is parked on s_waitcnt 69 % of its time (SQ_WAIT_ANY /
+ *     SQ_WAVE_CYCLES, profiles/r02_*), so four of them per SIMD raise the throughput although each is slower:
+ *     G=2048 8.2 M, G=4096 11.9 M MB/s (2 waves per SIMD: 8.4 M at G=2048; 3: 10.5 M at G=3072).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #define PCAMV_RD_TU 1
+#ifdef PCAMV_RD_LO
+#define PCAMV_RD_OCC 1
+#define RD_NAME(x) x##_lo
+#else
+#define PCAMV_RD_OCC 4
+#define RD_NAME(x) x
+#endif
 #include "pcamv_kernels.hip.h"
 
-void pcamv_launch_flow_rd(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl)
+void RD_NAME(pcamv_launch_flow_rd)(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl)
 {
     hipLaunchKernelGGL(k_analyse_flow_rd, dim3(waves), dim3(64), 0, st, dF, fl);
 }
-int pcamv_flow_rd_waves_per_cu(void)
+int RD_NAME(pcamv_flow_rd_waves_per_cu)(void)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow_rd, 64, 0) != hipSuccess) return -1;
@@ -24,10 +40,10 @@ int pcamv_flow_rd_waves_per_cu(void)
 }
 #ifdef PCAMV_PROF
 /* the phase timers are per translation unit (static __device__): this instance's */
-int pcamv_rd_prof_fetch(unsigned long long *out, int reset)
+int RD_NAME(pcamv_rd_prof_fetch)(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcamv_prof), sizeof(unsigned long long) * PCAMV_PROF_N) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[PCAMV_PROF_N] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pcamv_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif

@@ -129,8 +129,8 @@ def lib_path():
 
 
 def build_library(force=False):
-    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa instance, and csrc/pcamv_rd.hip,
-    the --subme 6 / 7 instance, compiled side by side) into the in-tree libpcamv_gpu.so."""
+    """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa instance, and csrc/pcamv_rd.hip + csrc/pcamv_rd_lo.hip,
+    the two builds of the --subme 6 / 7 instance, compiled side by side) into the in-tree libpcamv_gpu.so."""
     out = lib_path()
     srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if not f.endswith(".o")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "pcamv_gpu.h"))
@@ -138,7 +138,7 @@ def build_library(force=False):
         return out
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
     objs, procs = [], []
-    for unit in ("pcamv_gpu", "pcamv_tesa", "pcamv_rd"):
+    for unit in ("pcamv_gpu", "pcamv_tesa", "pcamv_rd", "pcamv_rd_lo"):
         obj = os.path.join(_CSRC, unit + ".o")
         objs.append(obj)
         procs.append(subprocess.Popen(["hipcc", *flags, "-c", "-o", obj, os.path.join(_CSRC, unit + ".hip")]))
@@ -172,10 +172,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def stc_extract(stego, m, height=10):
+class StcLcg:
+    """state of the reference's STC column generator (embed.h:134-139), carried from frame to frame by an extractor; a process --
+    a closed GOP under the per-GOP parity definition -- starts at 1"""
+
+    def __init__(self, state=1):
+        self.state = C.c_int64(state)
+
+
+def stc_extract(stego, m, height=10, lcg=None):
+    """message bits out of the stego bits; lcg (StcLcg) is needed, and advanced, for sub-matrix widths outside 2..20"""
     stego = np.ascontiguousarray(stego, np.uint8)
     msg = np.zeros(m, np.uint8)
-    rc = load_library().pcamv_gpu_stc_extract(_p(stego), len(stego), m, height, _p(msg))
+    rc = load_library().pcamv_gpu_stc_extract_lcg(_p(stego), len(stego), m, height, C.byref(lcg.state) if lcg is not None else None, _p(msg))
     if rc:
         raise PcamvError(f"pcamv_gpu_stc_extract failed: {rc}")
     return msg
@@ -377,6 +386,13 @@ class Batch:
     def set_closed_loop(self, on=True):
         if self.lib.pcamv_gpu_batch_set_closed_loop(self.b, int(on)):
             raise PcamvError("batch_set_closed_loop failed")
+
+    def copy_results_async(self, dst_mb, mb_stride, dst_flip=0, flip_stride=0, stream=0):
+        """records (and flip maps) of the step enqueued last to device or pinned host memory, on `stream`, without a host sync"""
+        rc = self.lib.pcamv_gpu_batch_copy_results_async(self.b, C.c_void_p(dst_mb), C.c_size_t(mb_stride), C.c_void_p(dst_flip or None),
+                                                         C.c_size_t(flip_stride), C.c_void_p(stream or None))
+        if rc:
+            raise PcamvError(f"batch_copy_results_async failed ({rc}): {self.lib.pcamv_gpu_batch_last_error(self.b).decode()}")
 
     def dominant_kernel(self):
         self.lib.pcamv_gpu_batch_dominant_kernel.restype = C.c_char_p
