@@ -595,14 +595,26 @@ static inline int prim_ssd_mb(const FrameDev &F, MBLocal *L)                /* s
 }
 /* the CABAC walk of one macroblock: a trial walks a copy of the slice's states, the committing walk the states themselves */
 struct CabWalk { uint8_t tmp[464]; uint8_t *S; int bits; };
-static inline void prim_cab_begin(MBLocal *L, CabWalk &C) { memcpy(C.tmp, L_CAB(L, 0), 464); C.S = C.tmp; C.bits = 0; }
+static inline void prim_cab_begin(MBLocal *L, CabWalk &C, int trial) { (void)trial; memcpy(C.tmp, L_CAB(L, 0), 464); C.S = C.tmp; C.bits = 0; }
 static inline void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx, int b)
 {
     const uint32_t w = L_CTAB(L)[2 * C.S[ctx] + b];
     C.S[ctx] = (uint8_t)(w & 255u); C.bits += (int)(w >> 8);
 }
 static inline void prim_cb_bypass(CabWalk &C, int f8) { C.bits += f8; }
-static inline int prim_cab_end(MBLocal *L, CabWalk &C, int commit) { if (commit) memcpy(L_CAB(L, 0), C.S, 464); return C.bits; }
+static inline int prim_cab_end(MBLocal *L, CabWalk &C, int commit) { if (commit) memcpy(L_CAB(L, 0), C.S, 464); else memcpy(L_CABT(L), C.S, PCAMV_CAB_USED); return C.bits; }
+static inline void prim_rd_keep(const FrameDev &F, MBLocal *L)
+{
+    memcpy(L->snap_pred, L->pred, 384); memcpy(L->snap_nzc, L->nzc, 48); memcpy(L->snap_cmvd, L->cmvd, sizeof(L->cmvd));
+    if (F.b_cabac) memcpy(L_CABK(L), L_CABT(L), PCAMV_CAB_USED);
+    L->snap_cbp_luma = L->cbp_luma; L->snap_cbp_chroma = L->cbp_chroma; L->snap_nnz_mask = L->nnz_mask;
+}
+static inline void prim_rd_restore(const FrameDev &F, MBLocal *L)
+{
+    memcpy(L->pred, L->snap_pred, 384); memcpy(L->nzc, L->snap_nzc, 48); memcpy(L->cmvd, L->snap_cmvd, sizeof(L->cmvd));
+    if (F.b_cabac) memcpy(L_CAB(L, 0), L_CABK(L), PCAMV_CAB_USED);
+    L->cbp_luma = L->snap_cbp_luma; L->cbp_chroma = L->snap_cbp_chroma; L->nnz_mask = L->snap_nnz_mask;
+}
 /* residual_block_cabac for every coded block of the macroblock (encoder/cabac.c:582-667, 1000-1018) */
 static inline void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit)
 {

@@ -151,13 +151,24 @@ struct MBLocal {
     int8_t i4mode[48];             /* h->mb.cache.intra4x4_pred_mode */
     int cbp_left, cbp_top;         /* h->mb.cache.i_cbp_left / top, -1 = unavailable */
     int b_fast_intra, fenc_satd_sum, fenc_sa8d_sum;
+    /* the RD trial that is the best so far, kept whole: what encoding + entropy-coding the macroblock as decided would produce
+     * again (reconstruction, non-zero flags / counts, MV differences, coded block pattern; the context states it ends in
+     * are kept in the window storage, L_CABK) */
+    uint8_t snap_pred[24 * 16];
+    uint8_t snap_nzc[48];
+    int16_t snap_cmvd[48][2];
+    int snap_cbp_luma, snap_cbp_chroma, snap_nnz_mask;
+    int snap_part, snap_cost;      /* partition (PCAMV_D_*) of the kept trial, -1 = none; its RD cost */
 };
 /* Storage that is idle while the RD decision runs is reused (no LDS growth): the RCA reference window holds the CABAC
  * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA
  * reconstruction buffers hold the intra 4x4 analysis' picture (17 rows of 32: row -1 and column -1 are the neighbours);
  * the P_SKIP probe's coefficient scratch (coef / cdc) holds a trial's quantised levels in scan order. */
-#define L_CAB(L, k) ((uint8_t *)(L)->win + 464 * (k))
-#define L_CTAB(L) ((L)->win + 232)
+#define L_CAB(L, k) ((uint8_t *)(L)->win + 464 * (k))      /* k = 0: the slice's states as the macroblock coded last left them */
+#define PCAMV_CAB_USED 276                                  /* contexts 0..275 are all a P slice of this path touches (coeff_abs_level_minus1 ends at 275) */
+#define L_CABT(L) ((uint8_t *)(L)->win + 464)               /* states at the end of the running size trial */
+#define L_CABK(L) ((uint8_t *)(L)->win + 464 + PCAMV_CAB_USED)  /* ... of the trial kept as the best so far */
+#define L_CTAB(L) ((L)->win + 256)
 #define L_IFD(L) ((uint8_t *)(L)->recb)
 #define IFD(L, x, y) (L_IFD(L)[((y) + 1) * 32 + (x) + 4])
 /* common/common.h:217-238: cache position of block idx (0..15 luma, 16..19 Cb, 20..23 Cr, 24 luma DC, 25 Cb DC, 26 Cr DC) */

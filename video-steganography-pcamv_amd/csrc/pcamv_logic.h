@@ -738,7 +738,7 @@ PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
     if (F.b_cabac) {
         const unsigned long long t_h = PROF_T();
         CabWalk C;
-        prim_cab_begin(L, C);                                /* a size trial: the slice's states are read, never written */
+        prim_cab_begin(L, C, 1);                             /* a size trial: the slice's states are read, never written */
         cabac_mb_header(F, L, C);
         PROF_ADD(20, t_h);
         const unsigned long long t_r = PROF_T();
@@ -750,28 +750,40 @@ PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
         bits = (int)((unsigned)prim_cavlc_mb(F, L) * (unsigned)F.lambda2 + 128u) >> 8;       /* int arithmetic in the reference */
     return ssd + bits;
 }
+/* One RD trial of the mode the cache describes.  The trials run in the order the decision compares them (16x16, 16x8, 8x16, 8x8,
+ * strict <), so the one that is the cheapest so far is the decision's winner as far as it has come: its products are kept
+ * (prim_rd_keep), and the macroblock as decided is not encoded and walked a second time when it is the kept one (mbk_search).
+ * counts = 0: a trial the decision will not look at (P_8x8 while nothing is embedded, analyse.c:2841). */
+PCAMV_DEV int rd_trial(const FrameDev &F, MBLocal *L, int counts)
+{
+    const int cost = rd_cost_mb(F, L);
+    if (counts && cost < L->snap_cost) { L->snap_cost = cost; L->snap_part = L->i_partition; prim_rd_keep(F, L); }
+    return cost;
+}
 PCAMV_DEV void analyse_p_rd(const FrameDev &F, MBLocal *L, struct Analysis *a, int i_satd)
 {
     const int thresh = i_satd * 5 / 4;
     L->i_type = PCAMV_P_L0;
-    if (a->rd16x16 == PCAMV_COST_MAX && a->me16x16.cost <= i_satd * 3 / 2) { L->i_partition = PCAMV_D_16x16; update_cache(L, a); a->rd16x16 = rd_cost_mb(F, L); }
+    if (a->rd16x16 == PCAMV_COST_MAX && a->me16x16.cost <= i_satd * 3 / 2) { L->i_partition = PCAMV_D_16x16; update_cache(L, a); a->rd16x16 = rd_trial(F, L, 1); }
     a->me16x16.cost = a->rd16x16;
-    if (a->cost16x8 <= thresh) { L->i_partition = PCAMV_D_16x8; update_cache(L, a); a->cost16x8 = rd_cost_mb(F, L); } else a->cost16x8 = PCAMV_COST_MAX;
-    if (a->cost8x16 <= thresh) { L->i_partition = PCAMV_D_8x16; update_cache(L, a); a->cost8x16 = rd_cost_mb(F, L); } else a->cost8x16 = PCAMV_COST_MAX;
-    if (a->cost8x8 <= thresh) { L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8; update_cache(L, a); a->cost8x8 = rd_cost_mb(F, L); } else a->cost8x8 = PCAMV_COST_MAX;
+    if (a->cost16x8 <= thresh) { L->i_partition = PCAMV_D_16x8; update_cache(L, a); a->cost16x8 = rd_trial(F, L, 1); } else a->cost16x8 = PCAMV_COST_MAX;
+    if (a->cost8x16 <= thresh) { L->i_partition = PCAMV_D_8x16; update_cache(L, a); a->cost8x16 = rd_trial(F, L, 1); } else a->cost8x16 = PCAMV_COST_MAX;
+    if (a->cost8x8 <= thresh) { L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8; update_cache(L, a); a->cost8x8 = rd_trial(F, L, F.embed); } else a->cost8x8 = PCAMV_COST_MAX;
 }
 /* what the entropy coder leaves behind for the following macroblocks (encoder.c:1900-1927, common/macroblock.c:1254-1400):
  * the context states adapted to the macroblock as coded, its non-zero flags / counts, coded block pattern and MV differences */
-PCAMV_DEV void entropy_commit(const FrameDev &F, MBLocal *L)
+/* walked = 1: the macroblock layer was walked already by the kept trial, whose end states, flags and MV differences have been
+ * restored (prim_rd_restore); what is left is the mb_skip_flag decision, whose context nothing else in a macroblock touches */
+PCAMV_DEV void entropy_commit(const FrameDev &F, MBLocal *L, int walked)
 {
     const int skip = L->i_type == PCAMV_P_SKIP;
     if (F.b_cabac) {
         CabWalk C;
-        prim_cab_begin(L, C);
+        prim_cab_begin(L, C, 0);
         prim_cb_dec(L, C, 11 + (L->type_left >= 0 && L->type_left != PCAMV_P_SKIP) + (L->type_top >= 0 && L->type_top != PCAMV_P_SKIP), skip);   /* x264_cabac_mb_skip */
-        if (!skip) { cabac_mb_header(F, L, C); prim_cab_residual(F, L, C, 1); }
+        if (!skip && !walked) { cabac_mb_header(F, L, C); prim_cab_residual(F, L, C, 1); }
         prim_cab_end(L, C, 1);                               /* the macroblock as coded: the adapted states are the slice's */
-    } else if (!skip) prim_cavlc_mb(F, L);
+    } else if (!skip && !walked) prim_cavlc_mb(F, L);
     prim_rd_commit(F, L, skip);
 }
 
@@ -801,7 +813,7 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
         if (me.mv[0] == L->pskip_mv[0] && me.mv[1] == L->pskip_mv[1]) {
             L->i_partition = PCAMV_D_16x16;
             cache_mv_set(L, 0, 0, 4, 4, me.mv[0], me.mv[1]);
-            a->rd16x16 = rd_cost_mb(F, L);
+            a->rd16x16 = rd_trial(F, L, 1);
         }
     }
     return 0;
@@ -1022,6 +1034,7 @@ PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
     L->i_partition = PCAMV_D_16x16;
     a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = PCAMV_COST_MAX;      /* analyse.c:321-332 */
+    L->snap_part = -1; L->snap_cost = PCAMV_COST_MAX;
     if (F.b_fast_pskip) {
         if (F.subme >= 3) b_try_pskip = 1;
         else if (L->type_left == PCAMV_P_SKIP || L->type_top == PCAMV_P_SKIP || L->type_topleft == PCAMV_P_SKIP || L->type_topright == PCAMV_P_SKIP)

@@ -33,13 +33,17 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
          * pass-1 reconstruction and the entropy coder's bookkeeping come before the hand-off */
         const unsigned long long t_c = PROF_T();
         L->b_skip_mc = 0;
-        mb_encode(F, L, 0, 1);
+        /* the trial of the decided mode has produced all of it already, unless no trial ran (P_SKIP, modes beyond the
+         * thresholds) or the kept one is another mode */
+        const int kept = L->i_type != PCAMV_P_SKIP && L->snap_part == L->i_partition;
+        if (kept) prim_rd_restore(F, L);
+        else mb_encode(F, L, 0, 1);
 #ifdef PCAMV_HOST_EMU
         prim_store_rec(F, L);
 #else
         prim_store_rec(F, L, true);
 #endif
-        entropy_commit(F, L);
+        entropy_commit(F, L, kept);
         PROF_ADD(22, t_c);
     }
     const unsigned long long t_w = PROF_T();

@@ -426,12 +426,17 @@ __device__ __forceinline__ uint32_t cab_tab(const CabWalk &C, int e)
     const int a = __builtin_amdgcn_readlane(C.t0, l), b = __builtin_amdgcn_readlane(C.t1, l), c = __builtin_amdgcn_readlane(C.t2, l), d = __builtin_amdgcn_readlane(C.t3, l);
     return (uint32_t)(e < 64 ? a : e < 128 ? b : e < 192 ? c : d);
 }
-__device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C)
+/* trial: a size trial -- its end states go to the trial copy (which starts as a copy of the slice's), never to the slice's */
+__device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C, int trial_)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     const uint8_t *S = L_CAB(L, 0);
     const uint32_t *T = L_CTAB(L);
+    if (rfl(trial_)) {
+        const uint32_t *s = (const uint32_t *)S; uint32_t *d = (uint32_t *)L_CABT(L);
+        d[lane] = s[lane]; if (lane < PCAMV_CAB_USED / 4 - 64) d[64 + lane] = s[64 + lane];
+    }
     C.s0 = S[lane]; C.s1 = lane < 24 ? S[64 + lane] : 0; C.bits = 0; C.vbits = 0;
     C.t0 = (int)T[lane]; C.t1 = (int)T[64 + lane]; C.t2 = (int)T[128 + lane]; C.t3 = (int)T[192 + lane];
 }
@@ -453,8 +458,8 @@ __device__ __forceinline__ void prim_cb_bypass(CabWalk &C, int f8) { C.bits += r
 __device__ __forceinline__ int prim_cab_end(MBLocal *L, CabWalk &C, int commit_)
 {
     const int lane = LANE();
-    if (rfl(commit_)) {
-        uint8_t *S = L_CAB(L, 0);
+    {
+        uint8_t *S = rfl(commit_) ? L_CAB(L, 0) : L_CABT(L);
         S[lane] = (uint8_t)C.s0;
         if (lane < 24) S[64 + lane] = (uint8_t)C.s1;
     }
@@ -480,6 +485,7 @@ __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L,
     (void)F;
     if (!(cbp_luma | cbp_chroma)) return;
     uint8_t *S = L_CAB(L, 0);
+    uint8_t *D = commit ? S : L_CABT(L);                 /* where the states the walk ends in go */
     const uint32_t *T = L_CTAB(L);
     int bits = 0, sbits = 0;            /* per-lane bits (map decisions, coded_block_flag chains) / wave-uniform bits (level chains) */
     const unsigned long long t_1 = PROF_T();
@@ -530,7 +536,7 @@ __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L,
             const uint32_t w = T[2 * st + (int)((flagm >> b) & 1u)];
             bits += (int)(w >> 8); st = (int)(w & 255u);
         }
-        if (commit) S[85 + 4 * (2 + cat) + k] = (uint8_t)st;
+        D[85 + 4 * (2 + cat) + k] = (uint8_t)st;
     }
     PROF_ADD(25, t_2);
     const unsigned long long t_3 = PROF_T();
@@ -585,10 +591,8 @@ __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L,
             sbits += 256 * __builtin_popcount(nz);       /* signs */
             PROF_CNT(30, __builtin_popcount(nz));
         }
-        if (commit) {
-            if (lane < cnt - 1) { S[sig_off + lane] = (uint8_t)sigS; S[last_off + lane] = (uint8_t)lastS; }
-            if (lane < 10) S[lvl_off + lane] = (uint8_t)lvlS;
-        }
+        if (lane < cnt - 1) { D[sig_off + lane] = (uint8_t)sigS; D[last_off + lane] = (uint8_t)lastS; }
+        if (lane < 10) D[lvl_off + lane] = (uint8_t)lvlS;
     }
     PROF_ADD(26, t_3);
     C.vbits += bits; C.bits += sbits;
@@ -695,6 +699,37 @@ __device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
 
 /* what the coded macroblock leaves for its neighbours and successors: bottom row / right column of the non-zero cache, coded
  * block pattern, MV differences, the slice's context states -- stored write-through, like the motion the search hands over */
+/* the trial just priced is the best so far: keep everything the final encode + entropy walk of that mode would produce again */
+__device__ __forceinline__ void prim_rd_keep(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    { const uint32_t *s = (const uint32_t *)L->pred; uint32_t *d = (uint32_t *)L->snap_pred; d[lane] = s[lane]; if (lane < 32) d[64 + lane] = s[64 + lane]; }
+    if (lane < 12) ((uint32_t *)L->snap_nzc)[lane] = ((const uint32_t *)L->nzc)[lane];
+    if (lane < 48) ((uint32_t *)L->snap_cmvd)[lane] = ((const uint32_t *)L->cmvd)[lane];
+    if (F.b_cabac) {
+        const uint32_t *s = (const uint32_t *)L_CABT(L); uint32_t *d = (uint32_t *)L_CABK(L);
+        d[lane] = s[lane]; if (lane < PCAMV_CAB_USED / 4 - 64) d[64 + lane] = s[64 + lane];
+    }
+    if (lane == 0) { L->snap_cbp_luma = L->cbp_luma; L->snap_cbp_chroma = L->cbp_chroma; L->snap_nnz_mask = L->nnz_mask; }
+    PCAMV_WAVE_SYNC();
+}
+/* the kept trial is the macroblock as decided: put its products where the final encode + walk would have left them (the context
+ * states become the slice's; the mb_skip_flag decision, which a size trial does not contain, is the caller's) */
+__device__ __forceinline__ void prim_rd_restore(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    { const uint32_t *s = (const uint32_t *)L->snap_pred; uint32_t *d = (uint32_t *)L->pred; d[lane] = s[lane]; if (lane < 32) d[64 + lane] = s[64 + lane]; }
+    if (lane < 12) ((uint32_t *)L->nzc)[lane] = ((const uint32_t *)L->snap_nzc)[lane];
+    if (lane < 48) ((uint32_t *)L->cmvd)[lane] = ((const uint32_t *)L->snap_cmvd)[lane];
+    if (F.b_cabac) {
+        const uint32_t *s = (const uint32_t *)L_CABK(L); uint32_t *d = (uint32_t *)L_CAB(L, 0);
+        d[lane] = s[lane]; if (lane < PCAMV_CAB_USED / 4 - 64) d[64 + lane] = s[64 + lane];
+    }
+    if (lane == 0) { L->cbp_luma = L->snap_cbp_luma; L->cbp_chroma = L->snap_cbp_chroma; L->nnz_mask = L->snap_nnz_mask; }
+    PCAMV_WAVE_SYNC();
+}
 __device__ __forceinline__ void prim_rd_commit(const FrameDev &F, MBLocal *L, int skip_)
 {
     const int skip = rfl(skip_);
