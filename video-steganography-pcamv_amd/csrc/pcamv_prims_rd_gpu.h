@@ -476,14 +476,26 @@ __device__ __forceinline__ int prim_cab_end(MBLocal *L, CabWalk &C, int commit_)
  *     coeff_flag[i] (one decision each per block, all positions at once), lane k < 10 owns coeff_abs_level_minus1 context k
  *     and takes the level chain's decisions as they come (non-zero levels only, from the last one down).
  * The per-block values of step 1 reach the wave-uniform control code of steps 2 / 3 through ballots and v_readlane. */
-__device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit_)
+/* The walk is a REAL function (PCAMV_RESIDUAL_CALL, the RD kernels): inlined into the decision code at 128 VGPRs its step 1
+ * alone carried 300 scratch reloads of values that were live around it and took 17 % of the search's wave time under load
+ * (1.6 M of 9.7 M cycles per macroblock at 4096 chains, against 2 % for the build without spills); as a callee it has the
+ * register file to itself, and what it exchanges with the caller is the table (4 registers) in, two bit counts out. */
+struct CabBits { int bits, vbits; };
+#ifdef PCAMV_RESIDUAL_CALL
+#define PCAMV_RESIDUAL_FN static __device__ __noinline__
+#else
+#define PCAMV_RESIDUAL_FN __device__ __forceinline__
+#endif
+PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2_, int t3_, int commit_)
 {
+    CabWalk C;
+    C.t0 = t0_; C.t1 = t1_; C.t2 = t2_; C.t3 = t3_; C.s0 = C.s1 = 0; C.bits = 0; C.vbits = 0;
+    CabBits out = {0, 0};
     const int commit = rfl(commit_);
     const int lane = LANE();
     PCAMV_WAVE_SYNC();
     const int cbp_luma = rfl(L->cbp_luma), cbp_chroma = rfl(L->cbp_chroma);
-    (void)F;
-    if (!(cbp_luma | cbp_chroma)) return;
+    if (!(cbp_luma | cbp_chroma)) return out;
     uint8_t *S = L_CAB(L, 0);
     uint8_t *D = commit ? S : L_CABT(L);                 /* where the states the walk ends in go */
     const uint32_t *T = L_CTAB(L);
@@ -505,19 +517,18 @@ __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L,
         if (flag) {
             const uint32_t *w = lane < 24 ? (const uint32_t *)L->coef[lane] : (const uint32_t *)L->cdc[lane - 24];
             const int nw = lane < 24 ? 8 : 2, sh = (lane >= 16 && lane < 24) ? 1 : 0;       /* chroma AC: scan position i is raw[i + 1] */
+            unsigned nzr = 0, g1r = 0;
+            unsigned long long nib = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const uint32_t v = j < nw ? w[j] : 0u;
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int lv = (int)(int16_t)(v >> (16 * h)), pos = 2 * j + h - sh;
-                    if (pos >= 0 && lv) {
-                        const int a = imin(iabs(lv), 15);
-                        nzm |= 1u << pos; gt1 |= (unsigned)(a > 1) << pos;
-                        if (pos < 8) nib0 |= (unsigned)a << (4 * pos); else nib1 |= (unsigned)a << (4 * (pos - 8));
-                    }
-                }
+                const unsigned a0 = (unsigned)imin(iabs((int)(int16_t)(v & 0xffffu)), 15), a1 = (unsigned)imin(iabs((int)v >> 16), 15);
+                nzr |= (unsigned)(a0 != 0) << (2 * j) | (unsigned)(a1 != 0) << (2 * j + 1);
+                g1r |= (unsigned)(a0 > 1) << (2 * j) | (unsigned)(a1 > 1) << (2 * j + 1);
+                nib |= (unsigned long long)(a0 | a1 << 4) << (8 * j);
             }
+            nzm = nzr >> sh; gt1 = g1r >> sh; nib >>= 4 * sh;
+            nib0 = (unsigned)nib; nib1 = (unsigned)(nib >> 32);
         }
     }
     const unsigned codedm = (unsigned)__ballot(coded), flagm = (unsigned)__ballot(flag != 0 && nzm != 0);
@@ -595,7 +606,14 @@ __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L,
         if (lane < 10) D[lvl_off + lane] = (uint8_t)lvlS;
     }
     PROF_ADD(26, t_3);
-    C.vbits += bits; C.bits += sbits;
+    out.vbits = bits; out.bits = sbits;
+    return out;
+}
+__device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit_)
+{
+    (void)F;
+    const CabBits r = cab_residual_walk(L, C.t0, C.t1, C.t2, C.t3, commit_);
+    C.vbits += r.vbits; C.bits += r.bits;
 }
 
 /* ---------------------------------------------------------------- CAVLC size of the macroblock layer */

@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #define PCAMV_RD_TU 1
+#ifndef PCAMV_NO_RESIDUAL_CALL
+#define PCAMV_RESIDUAL_CALL 1      /* pcamv_prims_rd_gpu.h: the CABAC residual walk as a function of its own */
+#endif
 #ifdef PCAMV_RD_LO
 #define PCAMV_RD_OCC 1
 #define RD_NAME(x) x##_lo
