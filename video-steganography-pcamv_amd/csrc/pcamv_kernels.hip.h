@@ -423,6 +423,7 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
      * reading the queue entry early as well gave nothing more) */
     unsigned ticket = 0;
     bool have_ticket = false;
+    PROF_INIT();
     for (;;) {
         const unsigned long long t_pop = PROF_T();
         unsigned idx = ticket;
@@ -496,13 +497,18 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         PROF_ADD(MODE ? 15 : 2, t_p);
         const unsigned long long t_r = PROF_T();
         if (MODE == 0 && fl.fused) {
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
-            have_ticket = true;
+            /* (not in raster order: a frame is then one chain, its next macroblock is the only work it has, and an entry bound to a
+             * ticket whose wave is still busy with this RCA step waits for it while free waves wait for later entries) */
+            if (!fl.raster) {
+                if (lane == 0) ticket = __hip_atomic_fetch_add(&fl.ctr[FLOW_HEAD(home)], 1u, RLX_AGENT);
+                have_ticket = true;
+            }
             mbk_rca_encode(F, &L, Ap, xy, 1, (TESA & 2) && F.b_mbrd);
         }
         PROF_ADD(3, t_r);
         if (MODE == 0) PROF_ADD(4, t_pop);
     }
+    PROF_FLUSH();
 }
 
 static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)

@@ -140,15 +140,19 @@ __device__ __forceinline__ int satd4x4_half(const uint32_t ec[8], const uint32_t
 
 /* mc_chroma (mc.c:246-277) of a 4x4 block: rows as 8-byte loads, the bilinear weights as one
  * v_dot4_u32_u8 per output pixel over the bytes {A[i], A[i+1], B[i], B[i+1]} */
-__device__ __forceinline__ void chroma_block4(gp8 cb, uint32_t cstride, uint32_t off, int mvx, int mvy, uint32_t r[4])
+__device__ __forceinline__ void chroma_rows_load(gp8 cb, uint32_t cstride, uint32_t off, uint64_t row[5])
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) row[k] = gld8(cb + (size_t)k * cstride, off);
+}
+__device__ __forceinline__ void chroma_block4_rows(const uint64_t row[5], int mvx, int mvy, uint32_t r[4])
 {
     const int dx = mvx & 7, dy = mvy & 7;
     const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
     uint32_t w[5][4];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        const uint64_t row = gld8(cb + (size_t)k * cstride, off);
-        const uint32_t lo = (uint32_t)row, hi = (uint32_t)(row >> 32);
+        const uint32_t lo = (uint32_t)row[k], hi = (uint32_t)(row[k] >> 32);
         w[k][0] = lo; w[k][1] = __builtin_amdgcn_alignbit(hi, lo, 8); w[k][2] = __builtin_amdgcn_alignbit(hi, lo, 16); w[k][3] = __builtin_amdgcn_alignbit(hi, lo, 24);
     }
 #pragma unroll
@@ -161,6 +165,12 @@ __device__ __forceinline__ void chroma_block4(gp8 cb, uint32_t cstride, uint32_t
         }
         r[k] = o;
     }
+}
+__device__ __forceinline__ void chroma_block4(gp8 cb, uint32_t cstride, uint32_t off, int mvx, int mvy, uint32_t r[4])
+{
+    uint64_t row[5];
+    chroma_rows_load(cb, cstride, off, row);
+    chroma_block4_rows(row, mvx, mvy, r);
 }
 
 /* ---- LDS reference window (RCA of a 16x16 macroblock) ---- */
@@ -356,15 +366,32 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
 }
 
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) { return (uint64_t)(uint32_t)rfl((int)(uint32_t)v) | (uint64_t)(uint32_t)rfl((int)(uint32_t)(v >> 32)) << 32; }
+#ifdef PCAMV_EVAL_CALL
+/* -DPCAMV_EVAL_CALL (off; kept for measurements): the list primitive as ONE real function (flags at run time; the descriptor
+ * fields it reads arrive as values and are made scalar again) instead of an inlined copy per call site (7 KB against ~600 KB
+ * of the kernel).  Measured slower both ways: a lone wave with every register 356 k against 282 k cycles per macroblock, the
+ * 4-waves-per-SIMD build 12.7 against 14.2 M MB/s at 4096 chains (fewer spills, 128 instead of 149, but 40 calls per macroblock
+ * each pay the callee-saved registers' round trip through scratch).  The CABAC residual walk, 2 calls per macroblock, is the
+ * opposite case (pcamv_prims_rd_gpu.h). */
+static __device__ __noinline__ EvalRes eval_list_fn(EvalEnv E, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int n, int flags, int mvp0, int mvp1)
+{
+    EvalEnv U;
+    U.cost_mv = (const int16_t *)rfl64((uint64_t)E.cost_mv); U.luma_base = (const uint8_t *)rfl64((uint64_t)E.luma_base); U.chroma_base = (const uint8_t *)rfl64((uint64_t)E.chroma_base);
+    U.plane_size = (long long)rfl64((uint64_t)E.plane_size); U.cplane_size = (long long)rfl64((uint64_t)E.cplane_size);
+    U.stride = rfl(E.stride); U.cstride = rfl(E.cstride); U.trace = (int *)rfl64((uint64_t)E.trace); U.trace_mb = rfl(E.trace_mb);
+    return eval_list_body(U, L, enc, ip, xoff, yoff, n, flags, mvp0, mvp1);
+}
+#endif
 __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int n, int flags, int mvp0, int mvp1)
 {
     EvalEnv E;
     E.cost_mv = F.cost_mv; E.luma_base = F.luma_base; E.chroma_base = F.chroma_base[0]; E.plane_size = F.plane_size; E.cplane_size = F.cplane_size;
     E.stride = F.stride; E.cstride = F.cstride; E.trace = F.trace; E.trace_mb = F.trace_mb;
-    /* (measured, round 2: making this one real function -- 7 KB instead of an inlined copy per call site, the kernel 30 %
-     * smaller -- made a lone wave SLOWER, 356k against 282k cycles per macroblock: the wave waits for the candidate pixels'
-     * load latency, not for instruction fetches, and a call adds the callee-saved registers' round trip through scratch) */
+#ifdef PCAMV_EVAL_CALL
+    return eval_list_fn(E, L, enc, ip, xoff, yoff, n, flags, mvp0, mvp1);
+#else
     return eval_list_body(E, L, enc, ip, xoff, yoff, n, flags, mvp0, mvp1);
+#endif
 }
 
 /* Exhaustive search window (me.c:489-622 without the ADS skip, see pcamv_logic.h): SAD + MV bits of every
