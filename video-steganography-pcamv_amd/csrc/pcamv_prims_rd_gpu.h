@@ -407,24 +407,44 @@ __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
 }
 
 /* ---------------------------------------------------------------- CABAC size / context walk of a macroblock */
-/* While a macroblock is walked, the state of every context it can touch lives in the lane that owns it: header contexts
- * 0..87 (mb_skip, mb_type, sub_mb_type, mvd, mb_qp_delta, coded_block_pattern) in lane ctx & 63 (two registers), the
- * residual contexts per block category as described at prim_cab_residual.  A decision is one table lookup (bits << 8 | next
- * state) by the owning lane; the bits are summed per lane and over the wave at the end.  The slice's states (LDS) are read
- * at the beginning and written back only by the committing walk. */
-struct CabWalk { int s0, s1, t0, t1, t2, t3, bits, vbits; };
-/* The walk's sequential decisions (macroblock header, level chains) run on the scalar side: the state is read out of its lane
- * (v_readlane), the (bits << 8 | next state) word comes out of the table held in four registers across the wave (entry e in
- * lane e & 63 of register e >> 6), the new state goes back with v_writelane, the bits add up in a scalar -- no memory round
- * trip on the chain (an LDS lookup per decision measured ~1500 cycles per coded block for a lone wave). */
-/* v_writelane by hand (this compiler has no builtin for it; in inline assembly it trips over the constant-bus rule): a compare +
- * select over the wave, the value coming from a scalar */
-__device__ __forceinline__ int lane_set(int old, int val, int lane_idx) { return LANE() == lane_idx ? val : old; }
-__device__ __forceinline__ uint32_t cab_tab(const CabWalk &C, int e)
+/* The size of a decision depends on the state of its context only, a context's state on the decisions made on THAT context only,
+ * and which decisions a macroblock makes (context, bin, order) on its syntax elements only -- never on a state.  So the walk has
+ * two halves.  The wave-uniform control code that follows the syntax (macroblock header; the level chains of the residual) does
+ * not look anything up: a decision is appended to the private queue of the lane that owns its context (64 bins in two
+ * registers + a count: a compare, a shift, an add).  Then every lane walks its own queue -- state -> (bits << 8 | next state)
+ * out of the table in LDS, one gather per step for ALL contexts at once -- so the length of the chain is the longest queue (the
+ * mvd contexts' 9 at most in a header; the level contexts' few dozen in a busy macroblock) instead of the number of decisions
+ * (30 .. 200), each of which used to be a dependent round of v_readlane / table select / write-back on the scalar side
+ * (15 k cycles per header, 28 k per residual of a lone wave's macroblock).  Header contexts 0..87 (mb_skip, mb_type, sub_mb_type,
+ * mvd, mb_qp_delta, coded_block_pattern): context c in lane c & 63 of register c >> 6.  The slice's states (LDS) are read at
+ * the beginning; the states the walk ends in go to the slice's (committing walk) or to the trial copy. */
+struct CabWalk { int s0, s1, n0, n1, bits, vbits; unsigned long long q0, q1; };
+__device__ __forceinline__ void cabq_push(unsigned long long &q, int &n, int owner, int bin)
 {
-    const int l = e & 63;
-    const int a = __builtin_amdgcn_readlane(C.t0, l), b = __builtin_amdgcn_readlane(C.t1, l), c = __builtin_amdgcn_readlane(C.t2, l), d = __builtin_amdgcn_readlane(C.t3, l);
-    return (uint32_t)(e < 64 ? a : e < 128 ? b : e < 192 ? c : d);
+    const bool me = LANE() == owner;
+    q |= me ? (unsigned long long)(unsigned)bin << n : 0ull;
+    n += me ? 1 : 0;
+}
+/* `ones` 1-bins followed, if `zero`, by one 0-bin: the unary prefix of a level */
+__device__ __forceinline__ void cabq_push_run(unsigned long long &q, int &n, int owner, int ones, int zero)
+{
+    const bool me = LANE() == owner;
+    q |= me ? ((1ull << ones) - 1ull) << n : 0ull;
+    n += me ? ones + zero : 0;
+}
+/* every lane walks its queue; returns the bits (8.8 fixed point) of this lane's decisions */
+__device__ __forceinline__ int cabq_resolve(const uint32_t *T, int &st, unsigned long long &q, int &n)
+{
+    int bits = 0;
+    while (__builtin_amdgcn_ballot_w64(n > 0)) {
+        if (n > 0) {
+            const uint32_t w = T[2 * st + (int)(q & 1ull)];
+            bits += (int)(w >> 8); st = (int)(w & 255u);
+            q >>= 1; n--;
+        }
+    }
+    q = 0;
+    return bits;
 }
 /* trial: a size trial -- its end states go to the trial copy (which starts as a copy of the slice's), never to the slice's */
 __device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C, int trial_)
@@ -432,32 +452,27 @@ __device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C, int trial
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     const uint8_t *S = L_CAB(L, 0);
-    const uint32_t *T = L_CTAB(L);
     if (rfl(trial_)) {
         const uint32_t *s = (const uint32_t *)S; uint32_t *d = (uint32_t *)L_CABT(L);
         d[lane] = s[lane]; if (lane < PCAMV_CAB_USED / 4 - 64) d[64 + lane] = s[64 + lane];
     }
     C.s0 = S[lane]; C.s1 = lane < 24 ? S[64 + lane] : 0; C.bits = 0; C.vbits = 0;
-    C.t0 = (int)T[lane]; C.t1 = (int)T[64 + lane]; C.t2 = (int)T[128 + lane]; C.t3 = (int)T[192 + lane];
+    C.q0 = C.q1 = 0; C.n0 = C.n1 = 0;
 }
 __device__ __forceinline__ void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx_, int b_)
 {
     const int ctx = rfl(ctx_), b = rfl(b_);
     (void)L;
-    if (ctx < 64) {
-        const uint32_t w = cab_tab(C, 2 * __builtin_amdgcn_readlane(C.s0, ctx) + b);
-        C.bits += (int)(w >> 8);
-        C.s0 = lane_set(C.s0, (int)(w & 255u), ctx);
-    } else {
-        const uint32_t w = cab_tab(C, 2 * __builtin_amdgcn_readlane(C.s1, ctx - 64) + b);
-        C.bits += (int)(w >> 8);
-        C.s1 = lane_set(C.s1, (int)(w & 255u), ctx - 64);
-    }
+    if (ctx < 64) cabq_push(C.q0, C.n0, ctx, b);           /* (a header makes fewer than 64 decisions in all: no queue can overflow) */
+    else cabq_push(C.q1, C.n1, ctx - 64, b);
 }
 __device__ __forceinline__ void prim_cb_bypass(CabWalk &C, int f8) { C.bits += rfl(f8); }
 __device__ __forceinline__ int prim_cab_end(MBLocal *L, CabWalk &C, int commit_)
 {
     const int lane = LANE();
+    const uint32_t *T = L_CTAB(L);
+    C.vbits += cabq_resolve(T, C.s0, C.q0, C.n0);
+    C.vbits += cabq_resolve(T, C.s1, C.q1, C.n1);
     {
         uint8_t *S = rfl(commit_) ? L_CAB(L, 0) : L_CABT(L);
         S[lane] = (uint8_t)C.s0;
@@ -486,10 +501,8 @@ struct CabBits { int bits, vbits; };
 #else
 #define PCAMV_RESIDUAL_FN __device__ __forceinline__
 #endif
-PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2_, int t3_, int commit_)
+PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_)
 {
-    CabWalk C;
-    C.t0 = t0_; C.t1 = t1_; C.t2 = t2_; C.t3 = t3_; C.s0 = C.s1 = 0; C.bits = 0; C.vbits = 0;
     CabBits out = {0, 0};
     const int commit = rfl(commit_);
     const int lane = LANE();
@@ -559,6 +572,7 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2
         const int cnt = pass == 0 ? 16 : pass == 1 ? 4 : 15;
         const int sig_off = pass == 0 ? 134 : pass == 1 ? 149 : 152, last_off = pass == 0 ? 195 : pass == 1 ? 210 : 213, lvl_off = pass == 0 ? 247 : pass == 1 ? 257 : 266;
         int sigS = lane < cnt - 1 ? S[sig_off + lane] : 0, lastS = lane < cnt - 1 ? S[last_off + lane] : 0, lvlS = lane < 10 ? S[lvl_off + lane] : 0;
+        unsigned long long lvlQ = 0; int lvlN = 0, lvl_tot = 0;
         for (; bm; bm &= bm - 1) {
             const int b = __builtin_ctz(bm);
             const unsigned nz = (unsigned)__builtin_amdgcn_readlane((int)nzm, b), g1 = (unsigned)__builtin_amdgcn_readlane((int)gt1, b);
@@ -570,14 +584,15 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2
                 bits += (int)(w1 >> 8); sigS = (int)(w1 & 255u);
                 if (sb) { bits += (int)(w2 >> 8); lastS = (int)(w2 & 255u); }
             }
-            /* levels from the last non-zero one down: node = min(#(|l| = 1) so far, 3) until a level above 1 was seen, then min(3 + #(|l| > 1), 7) */
+            /* levels from the last non-zero one down: node = min(#(|l| = 1) so far, 3) until a level above 1 was seen, then
+             * min(3 + #(|l| > 1), 7); the decisions go to the queues of the lanes that own the level contexts (lane k < 10) */
             int neq1 = 0, ngt1 = 0;
             for (unsigned m = nz; m;) {
                 const int i = 31 - __builtin_clz(m);
                 m &= ~(1u << i);
                 const int node = ngt1 ? imin(3 + ngt1, 7) : imin(neq1, 3);
                 const int c1 = node < 4 ? node + 1 : 0, c2 = node < 4 ? 5 : imin(node + 2, 9);
-                int st1 = __builtin_amdgcn_readlane(lvlS, c1);
+                if (lvl_tot > 64 - 16) { bits += cabq_resolve(T, lvlS, lvlQ, lvlN); lvl_tot = 0; }     /* no queue may pass 64 bins */
                 if ((g1 >> i) & 1u) {
                     int a = (int)(((i < 8 ? n0 : n1) >> (4 * (i & 7))) & 15u);
                     if (a == 15) {          /* 15 or more: the exact magnitude (escape suffix) from the block's levels */
@@ -585,23 +600,21 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2
                         a = rfl(iabs((int)l[i]));
                     }
                     const int am1 = a - 1, prefix = imin(am1, 14);
-                    uint32_t w = cab_tab(C, 2 * st1 + 1);
-                    sbits += (int)(w >> 8); lvlS = lane_set(lvlS, (int)(w & 255u), c1);
-                    int st2 = __builtin_amdgcn_readlane(lvlS, c2);
-                    for (int q = 0; q < prefix - 1; q++) { w = cab_tab(C, 2 * st2 + 1); sbits += (int)(w >> 8); st2 = (int)(w & 255u); }
-                    if (prefix < 14) { w = cab_tab(C, 2 * st2); sbits += (int)(w >> 8); st2 = (int)(w & 255u); }
-                    else sbits += size_ue_of((unsigned)(am1 - 14)) << 8;
-                    lvlS = lane_set(lvlS, st2, c2);
+                    cabq_push(lvlQ, lvlN, c1, 1);
+                    cabq_push_run(lvlQ, lvlN, c2, prefix - 1, prefix < 14);
+                    if (prefix >= 14) sbits += size_ue_of((unsigned)(am1 - 14)) << 8;
+                    lvl_tot += 1 + prefix;
                     ngt1++;
                 } else {
-                    const uint32_t w = cab_tab(C, 2 * st1);
-                    sbits += (int)(w >> 8); lvlS = lane_set(lvlS, (int)(w & 255u), c1);
+                    cabq_push(lvlQ, lvlN, c1, 0);
+                    lvl_tot++;
                     neq1++;
                 }
             }
             sbits += 256 * __builtin_popcount(nz);       /* signs */
             PROF_CNT(30, __builtin_popcount(nz));
         }
+        bits += cabq_resolve(T, lvlS, lvlQ, lvlN);
         if (lane < cnt - 1) { D[sig_off + lane] = (uint8_t)sigS; D[last_off + lane] = (uint8_t)lastS; }
         if (lane < 10) D[lvl_off + lane] = (uint8_t)lvlS;
     }
@@ -612,7 +625,7 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int t0_, int t1_, int t2
 __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit_)
 {
     (void)F;
-    const CabBits r = cab_residual_walk(L, C.t0, C.t1, C.t2, C.t3, commit_);
+    const CabBits r = cab_residual_walk(L, commit_);
     C.vbits += r.vbits; C.bits += r.bits;
 }
 
