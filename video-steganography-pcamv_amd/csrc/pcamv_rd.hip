@@ -11,10 +11,11 @@
  * budget only.  With CABAC a frame is ONE chain of macroblocks (the context states), so a batch of G GOPs keeps G waves busy
  * (+ the RCA work they hand off):
  *   - "lo", 1 wave per SIMD, up to 512 VGPRs, nothing spilled: the fastest macroblock.  Used while the chains fit the
- *     1024 SIMDs anyway (G <= 4 x CUs): G=64 1215 ms per 1080p step, G=1024 1485 ms = 5.6 M MB/s;
- *   - "hi", 4 waves per SIMD at 128 VGPRs (192 spilled): a wave is parked on s_waitcnt 69 % of its time (SQ_WAIT_ANY /
- *     SQ_WAVE_CYCLES, profiles/r02_*), so four of them per SIMD raise the throughput although each is slower:
- *     G=2048 8.2 M, G=4096 11.9 M MB/s (2 waves per SIMD: 8.4 M at G=2048; 3: 10.5 M at G=3072).
+ *     1024 SIMDs anyway (G <= 4 x CUs): G=64 928 ms per 1080p step (measured when the choice was made: G=1024 1485 ms = 5.6 M MB/s);
+ *   - "hi", 4 waves per SIMD at 128 VGPRs (149 spilled): a wave is parked on s_waitcnt 62 % of its time (SQ_WAIT_ANY /
+ *     SQ_WAVE_CYCLES, profiles/r02_*), so four of them per SIMD raise the throughput although each runs 1.8x slower:
+ *     G=4096 14.4 M MB/s (when the choice was made: G=2048 8.2 M, G=4096 11.9 M; 2 waves per SIMD 8.4 M at G=2048; 3: 10.5 M at
+ *     G=3072).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
