@@ -168,6 +168,16 @@ int pcamv_gpu_pass2_pframe(pcamv_ctx_t *ctx, const uint8_t *flips, int n_flips, 
 int pcamv_gpu_stc_extract(const uint8_t *stego, int n, int m, int matrixheight, uint8_t *message);
 int pcamv_gpu_stc_extract_lcg(const uint8_t *stego, int n, int m, int matrixheight, int64_t *lcg, uint8_t *message);
 
+/* H.264 MV-syntax extractor, the decode side of the BER check (the reference has none): parses the slice data
+ * of a CABAC-coded P slice -- the bytes from the first macroblock's mb_skip_flag on, i.e. after the slice header and its
+ * cabac_alignment bits, as encoder/cabac.c writes them (arithmetic decoding engine, mb_skip_flag, mb_type, sub_mb_type, mvd,
+ * coded_block_pattern, mb_qp_delta, the residual, end_of_slice_flag) -- and returns every macroblock's i_type, i_partition,
+ * i_sub_partition, ref[] and mv[] (MV prediction of H.264 8.4.1; P_SKIP inferred) in the record's layout; the other members are 0.
+ * Host code, no GPU needed.  Scope: what the P slices of this path contain (frame macroblocks, one reference so no ref_idx,
+ * 4x4 transform, cabac_init_idc 0): PCAMV_EUNSUP for an intra macroblock, PCAMV_EINVAL for a stream that does not end with
+ * the picture's last macroblock.  The carrier LSBs of the result go to pcamv_gpu_stc_extract*. */
+int pcamv_gpu_parse_pslice_cabac(const uint8_t *slice_data, size_t len, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb);
+
 /* Device-resident variants used by bench.py and the multi-frame pipeline: planes are raw
  * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */
 int pcamv_gpu_set_ref_device(pcamv_ctx_t *ctx, const void *y, const void *u, const void *v,

@@ -184,10 +184,42 @@ def rd_primitive_fixture():
     print("primitives_rd:", len(bufs), "predictions")
 
 
+def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, final=False):
+    """slice data of a P frame as the reference's own CABAC coder writes it (refh_slice_data) + what it coded: the golden input /
+    output of the product's MV-syntax extractor (pcamv_gpu_parse_pslice_cabac).  final: the frame's SECOND pass (flipped MVs) with
+    the message that was embedded, for the decode-side BER check -- 16x16 partitions only, where the reference's pass 2 is well
+    defined (tests/test_reference_pass2_quirks.py); otherwise the first pass, every partitioning."""
+    from pcamv_amd.synth import make_clip
+    clip = make_clip(W, H, 2, seed=seed, static_cols=static, noise=noise)
+    mvr = orc.level_mv_range(W, H)
+    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, cabac=1, embed=1, inter_flags=inter)
+    r.set_ref(*clip[0]); r.set_fenc(*clip[1])
+    mbs, _ = r.analyse_pframe(qp)
+    d = dict(width=W, height=H, qp=qp, final=int(final))
+    if final:
+        o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter & 0x31, cabac=1))
+        e = o.embed_pframe(mbs.view(orc.MB_DTYPE), 0.5)
+        o.close()
+        mbs2, _, _, _, _ = r.pass2_pframe((np.asarray(e["flip"]) == 1).astype(np.int8), qp)
+        d.update(used=mbs["used"], message=np.asarray(e["message"]), m=e["m"], n=e["n"])
+        mbs = mbs2
+    data = r.slice_data()
+    d.update(slice_data=np.frombuffer(data, np.uint8), type=mbs["type"], partition=mbs["partition"], sub_partition=mbs["sub_partition"], mv=mbs["mv"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, len(data), "bytes of slice data,", dict(zip(*np.unique(mbs["type"], return_counts=True))))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if not refh.available():
         sys.exit("oracle/_ref/libpcamv_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    if "--pslice-only" in sys.argv:
+        pslice_fixture("pslice_qcif_hex_subme5_final", 176, 144, "hex", 5, 26, 0x1 | 0x100, 5, 48, final=True)
+        pslice_fixture("pslice_cif_umh_subme7_final", 352, 288, "umh", 7, 26, 0x1 | 0x100, 6, 96, final=True)
+        pslice_fixture("pslice_cif_umh_subme7_partitions", 352, 288, "umh", 7, 22, 0x11, 13, 0, noise=12)
+        pslice_fixture("pslice_qcif_hex_subme6_qp34", 176, 144, "hex", 6, 34, 0x11, 9, 0, noise=30)
+        pslice_fixture("pslice_cif_dia_subme4_p4x4_qp16", 352, 288, "dia", 4, 16, 0x31, 21, 64, noise=25)
+        sys.exit(0)
     if "--rd-only" in sys.argv:
         rd_primitive_fixture()
         analysis_fixture("qcif_hex_subme6", 176, 144, "hex", 6, 26, 0x10, 5, 48)

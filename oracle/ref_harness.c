@@ -355,6 +355,21 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
     return 0;
 }
 
+/* The slice data the reference's entropy coder has produced for the frame analysed / re-encoded last: with CABAC the bytes from
+ * the first macroblock's mb_skip_flag to the end_of_slice terminal and the flush (x264_cabac_encode_flush, as x264_slice_write
+ * ends a slice, encoder.c:1332), i.e. what follows the slice header and its alignment bits.  Golden input of the product's
+ * MV-syntax extractor (tests/golden/pslice_*.npz).  Call once, after the frame. */
+int refh_slice_data(void *ctx, uint8_t *buf, int cap)
+{
+    refh_t *c = ctx; x264_t *h = c->h;
+    if (!h->param.b_cabac) return -1;
+    x264_cabac_encode_flush(h, &h->cabac);
+    int n = (int)(h->cabac.p - h->cabac.p_start);
+    if (n > cap) return -2;
+    memcpy(buf, h->cabac.p_start, n);
+    return n;
+}
+
 /* Pass 2 of the fork's two-pass P frame (encoder.c:2380-2390 re-enters x264_slice_write with firstTime = 0):
  * x264_macroblock_analyse forces type / partition / MVs from h->info.cache and swaps in mv_stego where
  * h->info.filp says so (analyse.c:2574-2577, 2658-2679, 2870-3107), x264_macroblock_encode reconstructs,

@@ -123,6 +123,15 @@ class Ref:
             raise RuntimeError("refh_pass2_pframe failed")
         return mbs, nnz, tuple(planes[:3]), tuple(planes[3:]), nmv
 
+    def slice_data(self):
+        """bytes the reference's CABAC coder wrote for the frame analysed / re-encoded last (from the first mb_skip_flag on)"""
+        buf = np.zeros(1 << 20, np.uint8)
+        lib().refh_slice_data.restype = C.c_int
+        n = lib().refh_slice_data(self.ctx, _p(buf), len(buf))
+        if n < 0:
+            raise RuntimeError(f"refh_slice_data: {n}")
+        return buf[:n].tobytes()
+
     def me_search(self, qp, mb_x, mb_y, pixel, xoff, yoff, mvp, mvc):
         mvp = np.asarray(mvp, np.int16)
         mvc = np.ascontiguousarray(np.asarray(mvc, np.int16).reshape(-1, 2))

@@ -1,0 +1,88 @@
+"""H.264 MV-syntax extractor (pcamv_gpu_parse_pslice_cabac: host code of the library, no GPU needed) -- the decode side of the BER
+check.  Golden inputs are slices as the REFERENCE's own CABAC coder wrote them (tests/golden/pslice_*.npz, minted by
+oracle/gen_golden.py --pslice-only through the harness); the parser must read back exactly what the reference coded:
+every macroblock's type, partition, sub-partitions and motion vectors (P_SKIP inferred, MV prediction of 8.4.1), for first-pass
+frames with every partitioning incl. p4x4, and for FINAL frames (flipped MVs) the payload comes back out of the parsed motion
+vectors with BER 0.  (Final frames only with 16x16 partitions: the gcc-built reference's second pass writes streams whose
+16x8 / 8x16 / P_8x8 macroblocks a decoder reads differently from the encoder's own state -- stale i_partition in its MV
+prediction)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "video-steganography-pcamv_amd"))
+import helpers  # noqa: E402
+
+FIXTURES = ["pslice_qcif_hex_subme5_final", "pslice_cif_umh_subme7_final", "pslice_cif_umh_subme7_partitions",
+            "pslice_qcif_hex_subme6_qp34", "pslice_cif_dia_subme4_p4x4_qp16"]
+
+
+def _parse(g):
+    import pcamv_amd
+    return pcamv_amd.parse_pslice_cabac(g["slice_data"].tobytes(), int(g["width"]) // 16, int(g["height"]) // 16, int(g["qp"]))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_parser_reads_back_what_the_reference_coded(name):
+    g = helpers.load(name)
+    got = _parse(g)
+    for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
+        bad = np.argwhere((g[a] != got[b]).reshape(len(got), -1).any(1)).ravel()
+        assert len(bad) == 0, f"{a} differs at macroblocks {bad[:8].tolist()} ({len(bad)} in all)"
+    assert (got["ref"] == 0).all()
+
+
+@pytest.mark.parametrize("name", [n for n in FIXTURES if n.endswith("_final")])
+def test_payload_comes_back_out_of_the_stream(name):
+    import pcamv_amd
+    g = helpers.load(name)
+    got = _parse(g)
+    got["used"] = g["used"]             # which macroblocks carry: every coded (not skipped) one (encoder.c:1566)
+    assert np.array_equal(got["used"] != 0, got["i_type"] != pcamv_amd.P_SKIP)
+    lsb = helpers.carrier_lsbs(got)
+    assert len(lsb) == int(g["n"])
+    msg = pcamv_amd.stc_extract(lsb, int(g["m"]))
+    assert np.array_equal(msg, g["message"]), "decode-side BER != 0"
+
+
+def test_damaged_streams_are_reported():
+    import pcamv_amd
+    g = helpers.load("pslice_qcif_hex_subme5_final")
+    data = g["slice_data"].tobytes()
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.parse_pslice_cabac(data[:len(data) // 2], 11, 9, 26)         # truncated: runs out before the last macroblock
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.parse_pslice_cabac(data, 11, 8, 26)                          # wrong picture size: end_of_slice in the wrong place
+    bad = bytearray(data); bad[40] ^= 0x55
+    try:                                                                        # a flipped byte: an error, or different motion -- never a crash
+        got = pcamv_amd.parse_pslice_cabac(bytes(bad), 11, 9, 26)
+        assert not np.array_equal(got["mv"], g["mv"])
+    except pcamv_amd.PcamvError:
+        pass
+
+
+def test_live_against_the_reference_coder():
+    """wherever the reference harness is built: more frames, chained (the second P frame predicts from the first one's motion)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import refh
+    if not refh.available():
+        pytest.skip("oracle/_ref/libpcamv_ref.so not built (needs /root/reference)")
+    import orc
+    import pcamv_amd
+    from pcamv_amd.synth import make_clip
+    for (W, H, me, subme, qp, inter, seed, static, noise) in [(320, 240, "hex", 6, 20, 0x11, 31, 64, 20), (176, 144, "umh", 5, 40, 0x31, 32, 0, 35),
+                                                              (352, 288, "esa", 3, 12, 0x31, 33, 96, 30)]:
+        clip = make_clip(W, H, 3, seed=seed, static_cols=static, noise=noise)
+        r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=orc.level_mv_range(W, H), cabac=1, embed=1, inter_flags=inter)
+        ref, prev = clip[0], (None, None)
+        for t in (1, 2):
+            r.set_ref(*ref, *prev); r.set_fenc(*clip[t])
+            mbs, rec = r.analyse_pframe(qp)
+            got = pcamv_amd.parse_pslice_cabac(r.slice_data(), W // 16, H // 16, qp)
+            for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
+                assert np.array_equal(mbs[a], got[b]), (W, H, me, t, a)
+            ref, prev = rec, helpers.mv_field(mbs["mv"], W // 16, H // 16)

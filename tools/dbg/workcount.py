@@ -9,13 +9,14 @@ from pcamv_amd.synth import make_clip
 import pcamv_amd
 W, H = 1920, 1088
 clip = make_clip(W, H, 3, seed=13)
-p = orc.make_params(W, H, me="umh", subme=5, mv_range=pcamv_amd.level_mv_range(W, H), tscale=256)
+SUBME = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+p = orc.make_params(W, H, me="umh", subme=SUBME, mv_range=pcamv_amd.level_mv_range(W, H), tscale=256, inter=0x11 if SUBME >= 6 else 0x10)
 o = orc.Oracle(p)
 o.set_ref(*clip[0]); 
 lib = C.CDLL(emu.build())
 st = (C.c_longlong * 32)()
 lib.emu_get_stats(st, 1)
-mbs, rec = emu.analyse_pframe(orc, p, 26, 1, list(clip[1]), o.ref_planes(), clip[0][1], clip[0][2], None, None, diag=2)
+mbs, rec = emu.analyse_pframe(orc, p, 26, 1, list(clip[1]), o.ref_planes(), clip[0][1], clip[0][2], None, None, diag=3 if SUBME >= 6 else 2)
 lib.emu_get_stats(st, 1)
 n = (W // 16) * (H // 16)
 names = ["fpel SAD", "qpel SAD", "SATD", "SATD+chroma"]

@@ -12,6 +12,7 @@
 #include <new>
 #include "pcamv_kernels.hip.h"
 #include "pcamv_host_tables.h"
+#include "pcamv_mvsyntax.h"
 
 #define PCAMV_ABI_VERSION 2
 #define NEV 32

@@ -172,6 +172,18 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def parse_pslice_cabac(slice_data, mb_w, mb_h, qp):
+    """pcamv_gpu_parse_pslice_cabac: the macroblock types, partitions and motion vectors a decoder reads out of a CABAC P slice"""
+    data = np.frombuffer(bytes(slice_data), np.uint8)
+    mbs = np.zeros(mb_w * mb_h, MB_DTYPE)
+    lib = load_library()
+    lib.pcamv_gpu_parse_pslice_cabac.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = lib.pcamv_gpu_parse_pslice_cabac(_p(data), len(data), mb_w, mb_h, qp, _p(mbs))
+    if rc:
+        raise PcamvError(f"pcamv_gpu_parse_pslice_cabac failed: {rc}")
+    return mbs
+
+
 class StcLcg:
     """state of the reference's STC column generator (embed.h:134-139), carried from frame to frame by an extractor; a process --
     a closed GOP under the per-GOP parity definition -- starts at 1"""
