@@ -177,6 +177,9 @@ int pcamv_gpu_stc_extract_lcg(const uint8_t *stego, int n, int m, int matrixheig
  * 4x4 transform, cabac_init_idc 0): PCAMV_EUNSUP for an intra macroblock, PCAMV_EINVAL for a stream that does not end with
  * the picture's last macroblock.  The carrier LSBs of the result go to pcamv_gpu_stc_extract*. */
 int pcamv_gpu_parse_pslice_cabac(const uint8_t *slice_data, size_t len, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb);
+/* the same for a CAVLC-coded P slice (--no-cabac): slice_data = from the first mb_skip_run to the rbsp trailing bits, as
+ * encoder/cavlc.c writes them (mb_skip_run, mb_type, sub_mb_type, mvd, coded_block_pattern, mb_qp_delta, residual_block_cavlc) */
+int pcamv_gpu_parse_pslice_cavlc(const uint8_t *slice_data, size_t len, int mb_w, int mb_h, pcamv_mb_t *out_mb);
 
 /* Device-resident variants used by bench.py and the multi-frame pipeline: planes are raw
  * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */

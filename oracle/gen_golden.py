@@ -184,7 +184,7 @@ def rd_primitive_fixture():
     print("primitives_rd:", len(bufs), "predictions")
 
 
-def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, final=False):
+def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, final=False, cabac=1):
     """slice data of a P frame as the reference's own CABAC coder writes it (refh_slice_data) + what it coded: the golden input /
     output of the product's MV-syntax extractor (pcamv_gpu_parse_pslice_cabac).  final: the frame's SECOND pass (flipped MVs) with
     the message that was embedded, for the decode-side BER check -- 16x16 partitions only, where the reference's pass 2 is well
@@ -192,12 +192,12 @@ def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, fina
     from pcamv_amd.synth import make_clip
     clip = make_clip(W, H, 2, seed=seed, static_cols=static, noise=noise)
     mvr = orc.level_mv_range(W, H)
-    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, cabac=1, embed=1, inter_flags=inter)
+    r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=mvr, cabac=cabac, embed=1, inter_flags=inter)
     r.set_ref(*clip[0]); r.set_fenc(*clip[1])
     mbs, _ = r.analyse_pframe(qp)
-    d = dict(width=W, height=H, qp=qp, final=int(final))
+    d = dict(width=W, height=H, qp=qp, final=int(final), cabac=cabac)
     if final:
-        o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter & 0x31, cabac=1))
+        o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter & 0x31, cabac=cabac))
         e = o.embed_pframe(mbs.view(orc.MB_DTYPE), 0.5)
         o.close()
         mbs2, _, _, _, _ = r.pass2_pframe((np.asarray(e["flip"]) == 1).astype(np.int8), qp)
@@ -219,6 +219,9 @@ if __name__ == "__main__":
         pslice_fixture("pslice_cif_umh_subme7_partitions", 352, 288, "umh", 7, 22, 0x11, 13, 0, noise=12)
         pslice_fixture("pslice_qcif_hex_subme6_qp34", 176, 144, "hex", 6, 34, 0x11, 9, 0, noise=30)
         pslice_fixture("pslice_cif_dia_subme4_p4x4_qp16", 352, 288, "dia", 4, 16, 0x31, 21, 64, noise=25)
+        pslice_fixture("pslice_cavlc_cif_umh_subme7_final", 352, 288, "umh", 7, 26, 0x1 | 0x100, 6, 96, final=True, cabac=0)
+        pslice_fixture("pslice_cavlc_cif_hex_subme5_p4x4_qp10", 352, 288, "hex", 5, 10, 0x31, 22, 160, noise=40, cabac=0)
+        pslice_fixture("pslice_cavlc_qcif_hex_subme6_qp34", 176, 144, "hex", 6, 34, 0x11, 9, 0, noise=30, cabac=0)
         sys.exit(0)
     if "--rd-only" in sys.argv:
         rd_primitive_fixture()

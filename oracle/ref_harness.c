@@ -52,6 +52,7 @@ typedef struct {
     int have_prev;
     uint32_t *dbg_state_hash;      /* optional [n_mb]: FNV-1a of the 460 CABAC context states after each macroblock was written */
     int dbg_mb; uint8_t *dbg_state;  /* optional: the 460 states after macroblock dbg_mb */
+    int tail_skip;                   /* CAVLC: skipped macroblocks at the end of the frame coded last (their run is written with the slice's end) */
     int dbg_rd_mb, dbg_rd_n; const int32_t *dbg_rd_in; int32_t *dbg_rd_out;   /* optional: RD cost of given candidates at one macroblock */
 } refh_t;
 
@@ -346,6 +347,7 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
             }
             x264_macroblock_cache_save(h);
         }
+    c->tail_skip = i_skip;
     x264_frame_t *f = h->fdec;
     for (int y = 0; y < c->height; y++) memcpy(rec_y + (size_t)y * c->width, f->plane[0] + (size_t)y * f->i_stride[0], c->width);
     for (int y = 0; y < c->height / 2; y++) {
@@ -362,7 +364,15 @@ int refh_analyse_pframe(void *ctx, int qp, refh_mb_t *out,
 int refh_slice_data(void *ctx, uint8_t *buf, int cap)
 {
     refh_t *c = ctx; x264_t *h = c->h;
-    if (!h->param.b_cabac) return -1;
+    if (!h->param.b_cabac) {        /* CAVLC: the run of skipped macroblocks that ends the slice, then the rbsp trailing bits (encoder.c:1320-1340) */
+        if (c->tail_skip > 0) bs_write_ue(&h->out.bs, c->tail_skip);
+        c->tail_skip = 0;
+        bs_rbsp_trailing(&h->out.bs);
+        int nb = bs_pos(&h->out.bs) / 8;
+        if (nb > cap) return -2;
+        memcpy(buf, h->out.p_bitstream, nb);
+        return nb;
+    }
     x264_cabac_encode_flush(h, &h->cabac);
     int n = (int)(h->cabac.p - h->cabac.p_start);
     if (n > cap) return -2;
@@ -415,6 +425,7 @@ int refh_pass2_pframe(void *ctx, int qp, const int8_t *flips, int n_flips, refh_
             o->pskip_mv[0] = h->mb.cache.pskip_mv[0]; o->pskip_mv[1] = h->mb.cache.pskip_mv[1];
             x264_macroblock_cache_save(h);
         }
+    c->tail_skip = i_skip;
     x264_frame_t *f = h->fdec;
     for (int pass = 0; pass < 2; pass++) {
         uint8_t *py = pass ? dbk_y : rec_y, *pu = pass ? dbk_u : rec_u, *pv = pass ? dbk_v : rec_v;

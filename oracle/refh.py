@@ -124,7 +124,8 @@ class Ref:
         return mbs, nnz, tuple(planes[:3]), tuple(planes[3:]), nmv
 
     def slice_data(self):
-        """bytes the reference's CABAC coder wrote for the frame analysed / re-encoded last (from the first mb_skip_flag on)"""
+        """bytes the reference's entropy coder wrote for the frame analysed / re-encoded last: CABAC from the first mb_skip_flag on,
+        CAVLC from the first mb_skip_run to the rbsp trailing bits"""
         buf = np.zeros(1 << 20, np.uint8)
         lib().refh_slice_data.restype = C.c_int
         n = lib().refh_slice_data(self.ctx, _p(buf), len(buf))

@@ -1,5 +1,5 @@
-"""H.264 MV-syntax extractor (pcamv_gpu_parse_pslice_cabac: host code of the library, no GPU needed) -- the decode side of the BER
-check.  Golden inputs are slices as the REFERENCE's own CABAC coder wrote them (tests/golden/pslice_*.npz, minted by
+"""H.264 MV-syntax extractor (pcamv_gpu_parse_pslice_cabac / _cavlc: host code of the library, no GPU needed) -- the decode side of the BER
+check.  Golden inputs are slices as the REFERENCE's own entropy coders (CABAC and CAVLC) wrote them (tests/golden/pslice_*.npz, minted by
 oracle/gen_golden.py --pslice-only through the harness); the parser must read back exactly what the reference coded:
 every macroblock's type, partition, sub-partitions and motion vectors (P_SKIP inferred, MV prediction of 8.4.1), for first-pass
 frames with every partitioning incl. p4x4, and for FINAL frames (flipped MVs) the payload comes back out of the parsed motion
@@ -18,11 +18,15 @@ sys.path.insert(0, os.path.join(ROOT, "video-steganography-pcamv_amd"))
 import helpers  # noqa: E402
 
 FIXTURES = ["pslice_qcif_hex_subme5_final", "pslice_cif_umh_subme7_final", "pslice_cif_umh_subme7_partitions",
-            "pslice_qcif_hex_subme6_qp34", "pslice_cif_dia_subme4_p4x4_qp16"]
+            "pslice_qcif_hex_subme6_qp34", "pslice_cif_dia_subme4_p4x4_qp16",
+            # --no-cabac: mb_skip_run, Exp-Golomb header, residual_block_cavlc (QP 10: level escapes)
+            "pslice_cavlc_cif_umh_subme7_final", "pslice_cavlc_cif_hex_subme5_p4x4_qp10", "pslice_cavlc_qcif_hex_subme6_qp34"]
 
 
 def _parse(g):
     import pcamv_amd
+    if "cabac" in g and not int(g["cabac"]):
+        return pcamv_amd.parse_pslice_cavlc(g["slice_data"].tobytes(), int(g["width"]) // 16, int(g["height"]) // 16)
     return pcamv_amd.parse_pslice_cabac(g["slice_data"].tobytes(), int(g["width"]) // 16, int(g["height"]) // 16, int(g["qp"]))
 
 
@@ -57,6 +61,11 @@ def test_damaged_streams_are_reported():
         pcamv_amd.parse_pslice_cabac(data[:len(data) // 2], 11, 9, 26)         # truncated: runs out before the last macroblock
     with pytest.raises(pcamv_amd.PcamvError):
         pcamv_amd.parse_pslice_cabac(data, 11, 8, 26)                          # wrong picture size: end_of_slice in the wrong place
+    v = helpers.load("pslice_cavlc_qcif_hex_subme6_qp34")["slice_data"].tobytes()
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.parse_pslice_cavlc(v[:len(v) // 2], 11, 9)
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.parse_pslice_cavlc(v, 11, 8)                                 # data left after the last macroblock
     bad = bytearray(data); bad[40] ^= 0x55
     try:                                                                        # a flipped byte: an error, or different motion -- never a crash
         got = pcamv_amd.parse_pslice_cabac(bytes(bad), 11, 9, 26)
@@ -77,12 +86,13 @@ def test_live_against_the_reference_coder():
     for (W, H, me, subme, qp, inter, seed, static, noise) in [(320, 240, "hex", 6, 20, 0x11, 31, 64, 20), (176, 144, "umh", 5, 40, 0x31, 32, 0, 35),
                                                               (352, 288, "esa", 3, 12, 0x31, 33, 96, 30)]:
         clip = make_clip(W, H, 3, seed=seed, static_cols=static, noise=noise)
-        r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=orc.level_mv_range(W, H), cabac=1, embed=1, inter_flags=inter)
-        ref, prev = clip[0], (None, None)
-        for t in (1, 2):
-            r.set_ref(*ref, *prev); r.set_fenc(*clip[t])
-            mbs, rec = r.analyse_pframe(qp)
-            got = pcamv_amd.parse_pslice_cabac(r.slice_data(), W // 16, H // 16, qp)
-            for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
-                assert np.array_equal(mbs[a], got[b]), (W, H, me, t, a)
-            ref, prev = rec, helpers.mv_field(mbs["mv"], W // 16, H // 16)
+        for cabac in (1, 0):
+            r = refh.Ref(W, H, qp=qp, me=me, subme=subme, mv_range=orc.level_mv_range(W, H), cabac=cabac, embed=1, inter_flags=inter)
+            ref, prev = clip[0], (None, None)
+            for t in (1, 2):
+                r.set_ref(*ref, *prev); r.set_fenc(*clip[t])
+                mbs, rec = r.analyse_pframe(qp)
+                got = pcamv_amd.parse_pslice_cabac(r.slice_data(), W // 16, H // 16, qp) if cabac else pcamv_amd.parse_pslice_cavlc(r.slice_data(), W // 16, H // 16)
+                for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
+                    assert np.array_equal(mbs[a], got[b]), (W, H, me, cabac, t, a)
+                ref, prev = rec, helpers.mv_field(mbs["mv"], W // 16, H // 16)

@@ -309,6 +309,193 @@ struct Parser {
         return 0;
     }
 };
+
+/* ---------------------------------------------------------------- CAVLC form (encoder/cavlc.c) */
+struct BitRd {
+    const uint8_t *d; size_t nbits, pos; int overrun;
+    unsigned peek(int n) const        /* the next n <= 24 bits, zero-filled past the end */
+    {
+        unsigned v = 0;
+        for (int i = 0; i < n; i++) { const size_t q = pos + (size_t)i; v = v << 1 | (q < nbits ? (unsigned)((d[q >> 3] >> (7 - (q & 7))) & 1) : 0u); }
+        return v;
+    }
+    unsigned get(int n) { const unsigned v = peek(n); pos += (size_t)n; if (pos > nbits) overrun++; return v; }
+    unsigned ue()
+    {
+        int z = 0;
+        while (!get(1)) if (++z > 24 || overrun) { overrun++; return 0; }
+        return ((1u << z) - 1u) + (z ? get(z) : 0u);
+    }
+    int se() { const unsigned k = ue(); return (k & 1) ? (int)((k + 1) >> 1) : -(int)(k >> 1); }
+};
+
+struct ParserV {
+    BitRd b;
+    int mb_w, mb_h;
+    int16_t *fmv; uint8_t *fnz; int8_t *ftype;      /* motion, total_coeff per 4x4 block [n_mb][24], types */
+    uint8_t cbp_of[48];                             /* codeNum -> coded_block_pattern (inverse of Table 9-4's inter column) */
+
+    /* one residual block (9.2): returns TotalCoeff.  tab: 0..3 by nC, 4 = chroma DC; maxc: 16, 15 or 4 */
+    int residual(int tab, int maxc)
+    {
+        int total = -1, t1 = 0;
+        if (b.peek(pcamv_vlc_coeff0_len[tab]) == pcamv_vlc_coeff0_code[tab]) { b.get(pcamv_vlc_coeff0_len[tab]); return 0; }
+        for (int tc = 1; tc <= (tab == 4 ? 4 : 16) && total < 0; tc++)
+            for (int tr = 0; tr <= (tc < 3 ? tc : 3); tr++) {
+                const int k = tab * 64 + (tc - 1) * 4 + tr, len = pcamv_vlc_coeff_len[k];
+                if (len && b.peek(len) == pcamv_vlc_coeff_code[k]) { b.get(len); total = tc; t1 = tr; break; }
+            }
+        if (total < 0 || total > maxc) { b.overrun++; return 0; }
+        int suffix_len = total > 10 && t1 < 3;
+        b.get(t1);                                                       /* signs of the trailing ones */
+        for (int i = t1; i < total; i++) {
+            int prefix = 0;
+            while (!b.get(1)) if (++prefix > 31 || b.overrun) { b.overrun++; return 0; }
+            const int ssize = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+            int code = ((prefix < 15 ? prefix : 15) << suffix_len) + (ssize ? (int)b.get(ssize) : 0);
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1 && t1 < 3) code += 2;
+            const int a = (code + 2) >> 1;                              /* |level| */
+            if (suffix_len == 0) suffix_len = 1;
+            if (a > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+        int zeros = 0;
+        if (total < maxc) {
+            const unsigned char *len = tab == 4 ? &pcamv_vlc_total_zeros_dc_len[(total - 1) * 4] : &pcamv_vlc_total_zeros_len[(total - 1) * 16];
+            const unsigned short *code = tab == 4 ? &pcamv_vlc_total_zeros_dc_code[(total - 1) * 4] : &pcamv_vlc_total_zeros_code[(total - 1) * 16];
+            int z, nz = tab == 4 ? 4 : 16;
+            for (z = 0; z < nz; z++) if (len[z] && b.peek(len[z]) == code[z]) { b.get(len[z]); break; }
+            if (z == nz) { b.overrun++; return 0; }
+            zeros = z;
+        }
+        for (int i = 0; i < total - 1 && zeros > 0; i++) {
+            const int zl = zeros - 1 < 6 ? zeros - 1 : 6;
+            int r;
+            for (r = 0; r < 16; r++) { const int len = pcamv_vlc_run_before_len[zl * 16 + r]; if (len && b.peek(len) == pcamv_vlc_run_before_code[zl * 16 + r]) { b.get(len); break; } }
+            if (r == 16 || r > zeros) { b.overrun++; return 0; }
+            zeros -= r;
+        }
+        return total;
+    }
+    void mvd(MbCache &C, int idx, int width, int height)
+    {
+        int mvp[2];
+        predict_mv(C, idx, width, mvp);
+        const int dx = b.se(), dy = b.se();
+        for (int j = 0; j < height; j++)
+            for (int i = 0; i < width; i++) {
+                const int q = s8(idx) + i + 8 * j;
+                C.mv[q][0] = (int16_t)(mvp[0] + dx); C.mv[q][1] = (int16_t)(mvp[1] + dy); C.ref[q] = 0;
+            }
+    }
+    int run(pcamv_mb_t *out)
+    {
+        static const uint8_t ct_index[17] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3};
+        for (int i = 0; i < 48; i++) cbp_of[pcamv_inter_cbp_to_golomb[i]] = (uint8_t)i;
+        int skip_run = -1;              /* -1: the next thing in the stream is an mb_skip_run */
+        for (int my = 0; my < mb_h; my++)
+            for (int mx = 0; mx < mb_w; mx++) {
+                const int xy = my * mb_w + mx, s4 = 4 * mb_w;
+                const bool left = mx > 0, top = my > 0, topleft = left && top, topright = top && mx < mb_w - 1;
+                MbCache C;
+                memset(&C, 0, sizeof(C));
+                memset(C.ref, -2, sizeof(C.ref));
+                memset(C.nz, 0x80, sizeof(C.nz));                         /* 0x80: not available (common/macroblock.c:1100-1160) */
+                C.partition = PCAMV_D_16x16;
+                auto take = [&](int q, int bx, int by) { const int16_t *m = fmv + 2 * (by * s4 + bx); C.mv[q][0] = m[0]; C.mv[q][1] = m[1]; C.ref[q] = 0; };
+                if (left) for (int j = 0; j < 4; j++) take(S8_0 - 1 + 8 * j, 4 * mx - 1, 4 * my + j);
+                if (top) for (int i = 0; i < 4; i++) take(S8_0 - 8 + i, 4 * mx + i, 4 * my - 1);
+                if (topleft) take(S8_0 - 8 - 1, 4 * mx - 1, 4 * my - 1);
+                if (topright) take(S8_0 - 8 + 4, 4 * mx + 4, 4 * my - 1);
+                if (left) { const uint8_t *z = fnz + 24 * (xy - 1);
+                    C.nz[nzc_pos(0) - 1] = z[5]; C.nz[nzc_pos(2) - 1] = z[7]; C.nz[nzc_pos(8) - 1] = z[13]; C.nz[nzc_pos(10) - 1] = z[15];
+                    C.nz[nzc_pos(16) - 1] = z[17]; C.nz[nzc_pos(18) - 1] = z[19]; C.nz[nzc_pos(20) - 1] = z[21]; C.nz[nzc_pos(22) - 1] = z[23]; }
+                if (top) { const uint8_t *z = fnz + 24 * (xy - mb_w);
+                    C.nz[nzc_pos(0) - 8] = z[10]; C.nz[nzc_pos(1) - 8] = z[11]; C.nz[nzc_pos(4) - 8] = z[14]; C.nz[nzc_pos(5) - 8] = z[15];
+                    C.nz[nzc_pos(16) - 8] = z[18]; C.nz[nzc_pos(17) - 8] = z[19]; C.nz[nzc_pos(20) - 8] = z[22]; C.nz[nzc_pos(21) - 8] = z[23]; }
+                for (int i = 0; i < 24; i++) C.nz[nzc_pos(i)] = 0;
+                pcamv_mb_t *o = &out[xy];
+                memset(o, 0, sizeof(*o));
+                for (int i = 0; i < 4; i++) o->i_sub_partition[i] = PCAMV_D_L0_8x8;
+                o->i_partition = PCAMV_D_16x16;
+                uint8_t nzb[24];
+                memset(nzb, 0, sizeof(nzb));
+                if (skip_run < 0) skip_run = (int)b.ue();
+                if (skip_run > 0) {
+                    skip_run--;
+                    int mv[2];
+                    predict_pskip(C, mv);
+                    for (int i = 0; i < 16; i++) { C.mv[s8(i)][0] = (int16_t)mv[0]; C.mv[s8(i)][1] = (int16_t)mv[1]; }
+                    o->i_type = PCAMV_P_SKIP;
+                    o->pskip_mv[0] = (int16_t)mv[0]; o->pskip_mv[1] = (int16_t)mv[1];
+                    /* (when the run is used up the next macroblock is a coded one: no new run is read before it) */
+                } else {
+                    skip_run = -1;
+                    const unsigned mt = b.ue();
+                    if (mt > 4) return PCAMV_EUNSUP;                    /* an intra macroblock in a P slice */
+                    uint8_t sub[4] = {PCAMV_D_L0_8x8, PCAMV_D_L0_8x8, PCAMV_D_L0_8x8, PCAMV_D_L0_8x8};
+                    if (mt >= 3) {
+                        static const uint8_t sub_of[4] = {PCAMV_D_L0_8x8, PCAMV_D_L0_8x4, PCAMV_D_L0_4x8, PCAMV_D_L0_4x4};
+                        o->i_type = PCAMV_P_8x8; o->i_partition = PCAMV_D_8x8; C.partition = PCAMV_D_8x8;
+                        for (int i = 0; i < 4; i++) { const unsigned st = b.ue(); if (st > 3) return PCAMV_EINVAL; sub[i] = sub_of[st]; }
+                        for (int i = 0; i < 4; i++)
+                            switch (sub[i]) {
+                            case PCAMV_D_L0_8x8: mvd(C, 4 * i, 2, 2); break;
+                            case PCAMV_D_L0_8x4: mvd(C, 4 * i, 2, 1); mvd(C, 4 * i + 2, 2, 1); break;
+                            case PCAMV_D_L0_4x8: mvd(C, 4 * i, 1, 2); mvd(C, 4 * i + 1, 1, 2); break;
+                            default: for (int k = 0; k < 4; k++) mvd(C, 4 * i + k, 1, 1); break;
+                            }
+                        memcpy(o->i_sub_partition, sub, 4);
+                    } else {
+                        o->i_type = PCAMV_P_L0;
+                        o->i_partition = mt == 0 ? PCAMV_D_16x16 : mt == 1 ? PCAMV_D_16x8 : PCAMV_D_8x16;
+                        C.partition = o->i_partition;
+                        if (mt == 0) mvd(C, 0, 4, 4);
+                        else if (mt == 1) { mvd(C, 0, 4, 2); mvd(C, 8, 4, 2); }
+                        else { mvd(C, 0, 2, 4); mvd(C, 4, 2, 4); }
+                    }
+                    const unsigned cn = b.ue();
+                    if (cn > 47) return PCAMV_EINVAL;
+                    const int cbp = cbp_of[cn], cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
+                    if (cbp) {
+                        b.se();                                         /* mb_qp_delta */
+                        for (int i = 0; i < 16; i++)
+                            if ((cbp_luma >> (i >> 2)) & 1) {
+                                const int q = nzc_pos(i);
+                                int nc = C.nz[q - 1] + C.nz[q - 8];
+                                if (nc < 0x80) nc = (nc + 1) >> 1;
+                                nzb[i] = (uint8_t)residual(ct_index[nc & 0x7f], 16);
+                                C.nz[q] = nzb[i];
+                            }
+                        if (cbp_chroma) {
+                            residual(4, 4); residual(4, 4);
+                            if (cbp_chroma & 2)
+                                for (int i = 16; i < 24; i++) {
+                                    const int q = nzc_pos(i);
+                                    int nc = C.nz[q - 1] + C.nz[q - 8];
+                                    if (nc < 0x80) nc = (nc + 1) >> 1;
+                                    nzb[i] = (uint8_t)residual(ct_index[nc & 0x7f], 15);
+                                    C.nz[q] = nzb[i];
+                                }
+                        }
+                    }
+                }
+                for (int i = 0; i < 16; i++) {
+                    const int bx = 4 * mx + blk_x(i), by = 4 * my + blk_y(i), q = s8(i);
+                    fmv[2 * (by * s4 + bx)] = C.mv[q][0]; fmv[2 * (by * s4 + bx) + 1] = C.mv[q][1];
+                    o->mv[i][0] = C.mv[q][0]; o->mv[i][1] = C.mv[q][1]; o->ref[i] = 0;
+                }
+                memcpy(fnz + 24 * xy, nzb, 24);
+                ftype[xy] = (int8_t)o->i_type;
+                if (b.overrun) return PCAMV_EINVAL;
+            }
+        /* rbsp_slice_trailing_bits: a 1 and zeros up to the byte boundary, within the last byte(s) handed over */
+        if (b.pos >= b.nbits || !b.get(1)) return PCAMV_EINVAL;
+        while (b.pos < b.nbits) if (b.get(1)) return PCAMV_EINVAL;
+        return 0;
+    }
+};
 }   /* namespace mvsyntax */
 
 extern "C" int pcamv_gpu_parse_pslice_cabac(const uint8_t *data, size_t len, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb)
@@ -325,6 +512,21 @@ extern "C" int pcamv_gpu_parse_pslice_cabac(const uint8_t *data, size_t len, int
         rc = P.run(out_mb);
     }
     free(P.fmv); free(P.fmvd); free(P.fnz); free(P.fcbp); free(P.ftype);
+    return rc;
+}
+extern "C" int pcamv_gpu_parse_pslice_cavlc(const uint8_t *data, size_t len, int mb_w, int mb_h, pcamv_mb_t *out_mb)
+{
+    if (!data || !out_mb || len < 1 || mb_w < 1 || mb_h < 1) return PCAMV_EINVAL;
+    const size_t n = (size_t)mb_w * mb_h;
+    mvsyntax::ParserV P;
+    P.mb_w = mb_w; P.mb_h = mb_h;
+    P.fmv = (int16_t *)calloc(n * 32, sizeof(int16_t)); P.fnz = (uint8_t *)calloc(n * 24, 1); P.ftype = (int8_t *)calloc(n, 1);
+    int rc = PCAMV_ENOMEM;
+    if (P.fmv && P.fnz && P.ftype) {
+        P.b.d = data; P.b.nbits = len * 8; P.b.pos = 0; P.b.overrun = 0;
+        rc = P.run(out_mb);
+    }
+    free(P.fmv); free(P.fnz); free(P.ftype);
     return rc;
 }
 #endif

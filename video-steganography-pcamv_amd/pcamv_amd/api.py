@@ -184,6 +184,18 @@ def parse_pslice_cabac(slice_data, mb_w, mb_h, qp):
     return mbs
 
 
+def parse_pslice_cavlc(slice_data, mb_w, mb_h):
+    """pcamv_gpu_parse_pslice_cavlc: the same out of a CAVLC P slice"""
+    data = np.frombuffer(bytes(slice_data), np.uint8)
+    mbs = np.zeros(mb_w * mb_h, MB_DTYPE)
+    lib = load_library()
+    lib.pcamv_gpu_parse_pslice_cavlc.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    rc = lib.pcamv_gpu_parse_pslice_cavlc(_p(data), len(data), mb_w, mb_h, _p(mbs))
+    if rc:
+        raise PcamvError(f"pcamv_gpu_parse_pslice_cavlc failed: {rc}")
+    return mbs
+
+
 class StcLcg:
     """state of the reference's STC column generator (embed.h:134-139), carried from frame to frame by an extractor; a process --
     a closed GOP under the per-GOP parity definition -- starts at 1"""
