@@ -18,6 +18,9 @@ def sha(a):
 
 @pytest.fixture(scope="module")
 def pc():
+    import torch
+    torch.cuda.init()                   # the tests that hand device tensors to the library: torch's lazy HIP initialisation, done late
+    #                                     (after the library's own HIP calls, in some test orders), found "No HIP GPUs"
     import pcamv_amd
     pcamv_amd.load_library()            # fails loudly if the HIP library is missing
     return pcamv_amd

@@ -159,6 +159,11 @@ struct MBLocal {
     int16_t snap_cmvd[48][2];
     int snap_cbp_luma, snap_cbp_chroma, snap_nnz_mask;
     int snap_part, snap_cost;      /* partition (PCAMV_D_*) of the kept trial, -1 = none; its RD cost */
+#ifdef PCAMV_SEARCH_CALL           /* the motion search as a callee (pcamv_logic.h): its arguments pass through here */
+    const struct FrameDev *fdesc;  /* this macroblock's frame descriptor in the descriptor array (constant memory) */
+    int me_tmp[10];                /* MEState */
+    int mvc_tmp[9][2];
+#endif
 };
 /* Storage that is idle while the RD decision runs is reused (no LDS growth): the RCA reference window holds the CABAC
  * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA

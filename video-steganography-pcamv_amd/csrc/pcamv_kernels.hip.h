@@ -467,6 +467,9 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         if (MODE == 0) PROF_ADD(15, t_f);
         PROF_ADD(MODE ? 13 : 0, t_pop);
         const unsigned long long t_s = PROF_T();
+#ifdef PCAMV_SEARCH_CALL
+        if (MODE == 0 && lane == 0) L.fdesc = Fs + g;
+#endif
         if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
         else {
             for (int k = 0; k < fl.unit; k++) {

@@ -359,7 +359,44 @@ PCAMV_DEV void tesa_search(const FrameDev &F, MBLocal *L, MEState *me, int &bmx,
 }
 
 template <int TESA>
+PCAMV_DEV void me_search_body(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc);
+#if defined(PCAMV_SEARCH_CALL) && !defined(PCAMV_HOST_EMU)
+/* -DPCAMV_SEARCH_CALL (off; kept for measurements): the search of one partition as a REAL function -- 5 to 9 calls per
+ * macroblock, inside which the register file is the search's alone; the arguments go through LDS, the frame descriptor is read
+ * again from constant memory (a reference to the caller's copy would pin that copy in scratch).  Measured in the
+ * 4-waves-per-SIMD build of the RD kernel: 13.7 against 14.4 M MB/s at 4096 chains -- the callee spills as much as the inlined
+ * code did (195 against 149 registers over caller + callee), and the descriptor reload and the LDS hand-over are new. */
+template <int TESA>
+static __device__ __noinline__ void me_search_fn(MBLocal *L, int i_mvc_)
+{
+    const unsigned long long fp = (unsigned long long)L->fdesc;
+    const __attribute__((address_space(4))) unsigned *src = (const __attribute__((address_space(4))) unsigned *)
+        (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)fp));
+    FrameDev Fm;
+    unsigned *dst = (unsigned *)&Fm;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(FrameDev) / 4); i++) dst[i] = src[i];
+    const FrameDev &F = Fm;
+    me_search_body<TESA>(F, L, (MEState *)L->me_tmp, L->mvc_tmp, __builtin_amdgcn_readfirstlane(i_mvc_));
+}
+template <int TESA>
 PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc)
+{
+    (void)F;
+    PCAMV_WAVE_SYNC();
+    *(MEState *)L->me_tmp = *me;
+    for (int i = 0; i < i_mvc; i++) { L->mvc_tmp[i][0] = mvc[i][0]; L->mvc_tmp[i][1] = mvc[i][1]; }
+    PCAMV_WAVE_SYNC();
+    me_search_fn<TESA>(L, i_mvc);
+    PCAMV_WAVE_SYNC();
+    *me = *(MEState *)L->me_tmp;
+}
+#else
+template <int TESA>
+PCAMV_DEV void me_search(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc) { me_search_body<TESA>(F, L, me, mvc, i_mvc); }
+#endif
+template <int TESA>
+PCAMV_DEV void me_search_body(const FrameDev &F, MBLocal *L, MEState *me, int (*mvc)[2], int i_mvc)
 {
     const int ip = me->i_pixel;
     int i_me_range = F.me_range;
