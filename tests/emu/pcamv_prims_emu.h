@@ -414,6 +414,9 @@ static inline void prim_rd_load(const FrameDev &F, MBLocal *L)
     }
     L->b_fast_intra = xy > 4 && F.ref_is_inter;          /* analyse.c:363-378 */
 }
+struct MbFetch { int unused; };
+static inline void prim_mb_fetch(const FrameDev &, int, int, int, int, MbFetch &) {}
+static inline void prim_mb_fetch_store(const FrameDev &F, MBLocal *L, int rd, const MbFetch &) { prim_load_fenc(F, L); if (rd) prim_rd_load(F, L); }
 #define EF1(a, b) (((a) + (b) + 1) >> 1)
 #define EF2(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
 /* H.264 8.3.1.2 / 8.3.3 / 8.3.4 from explicit neighbour arrays: top[-1] is the top-left sample */

@@ -223,8 +223,10 @@ struct EvalRes { int cost, idx; };
 /* lane-parallel generation of a candidate list: the body runs once per candidate index c < n (n <= 64) */
 #ifdef PCAMV_HOST_EMU
 #define FOR_CAND(c, n) for (int c = 0; c < (n); c++)
+#define NB_SLOT(i) (i)          /* where iteration i of a FOR_CAND loop keeps a value for a later FOR_CAND loop: element i on the CPU */
 #else
 #define FOR_CAND(c, n) for (int c = (int)(threadIdx.x & 63), c##_1 = 1; c##_1 && c < (n); c##_1 = 0)
+#define NB_SLOT(i) 0           /* ... the lane's own register on the GPU (the body runs once per lane) */
 #endif
 
 /* Stores of the bytes other wavefronts read inside the same launch (a macroblock's final motion, read by its right

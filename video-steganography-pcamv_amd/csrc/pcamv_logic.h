@@ -114,33 +114,49 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
 {
     L->mb_x = mb_x; L->mb_y = mb_y; L->mb_xy = mb_y * F.mb_w + mb_x;
     L->b_skip_mc = 0;
-    L->neighbour = 0;
-    L->type_left = L->type_top = L->type_topleft = L->type_topright = -1;
+    MbFetch pf;
     if (!lite) {
-    int top = L->mb_xy - F.mb_w;
-    if (mb_y > 0) { L->neighbour |= NB_TOP; L->type_top = NB_LD8(&F.mb_type[top]); }
-    if (mb_x > 0) { L->neighbour |= NB_LEFT; L->type_left = NB_LD8(&F.mb_type[L->mb_xy - 1]); }
-    if (mb_x < F.mb_w - 1 && mb_y > 0) { L->neighbour |= NB_TOPRIGHT; L->type_topright = NB_LD8(&F.mb_type[top + 1]); }
-    if (mb_x > 0 && mb_y > 0) { L->neighbour |= NB_TOPLEFT; L->type_topleft = NB_LD8(&F.mb_type[top - 1]); }
+    /* every load the macroblock needs is ISSUED before the first of them is used (types and motion of the neighbours here,
+     * source pixels and the RD decision's neighbourhood in prim_mb_fetch): one memory round trip on the macroblock chain */
+    const int top = L->mb_xy - F.mb_w;
+    const int nb = (mb_y > 0 ? NB_TOP : 0) | (mb_x > 0 ? NB_LEFT : 0) | (mb_x < F.mb_w - 1 && mb_y > 0 ? NB_TOPRIGHT : 0) | (mb_x > 0 && mb_y > 0 ? NB_TOPLEFT : 0);
+    int t_top = -1, t_left = -1, t_tr = -1, t_tl = -1;
+    if (nb & NB_TOP) t_top = NB_LD8(&F.mb_type[top]);
+    if (nb & NB_LEFT) t_left = NB_LD8(&F.mb_type[L->mb_xy - 1]);
+    if (nb & NB_TOPRIGHT) t_tr = NB_LD8(&F.mb_type[top + 1]);
+    if (nb & NB_TOPLEFT) t_tl = NB_LD8(&F.mb_type[top - 1]);
+    const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
+    const int b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+    const int t4 = (4 * (mb_y - 1) + 3) * s4 + 4 * mb_x, t8 = (2 * (mb_y - 1) + 1) * s8 + 2 * mb_x;
+    /* the ten neighbouring 4x4 motion entries, one per lane: 0 top-left, 1..4 top, 5 top-right, 6..9 left */
+    uint32_t nb_w[10]; int nb_r[10], nb_c8[10];       /* (one element per lane on the GPU: FOR_CAND's body runs once per lane) */
+    FOR_CAND(i, 10) {
+        int ok, c8, m4, r8;
+        if (i == 0) { ok = nb & NB_TOPLEFT; c8 = SCAN8_0 - 1 - 8; m4 = t4 - 1; r8 = t8 - 1; }
+        else if (i <= 4) { ok = nb & NB_TOP; c8 = SCAN8_0 - 8 + (i - 1); m4 = t4 + (i - 1); r8 = t8 + ((i - 1) >> 1); }
+        else if (i == 5) { ok = nb & NB_TOPRIGHT; c8 = SCAN8_0 + 4 - 8; m4 = t4 + 4; r8 = t8 + 2; }
+        else { ok = nb & NB_LEFT; c8 = SCAN8_0 - 1 + 8 * (i - 6); m4 = b4 - 1 + (i - 6) * s4; r8 = b8 - 1 + ((i - 6) >> 1) * s8; }
+        nb_c8[NB_SLOT(i)] = ok ? c8 : -1; nb_w[NB_SLOT(i)] = 0; nb_r[NB_SLOT(i)] = -2;
+        if (ok) { nb_w[NB_SLOT(i)] = NB_LD32(&F.mv[2 * m4]); nb_r[NB_SLOT(i)] = NB_LD8(&F.ref8[r8]); }
+    }
+    prim_mb_fetch(F, mb_x, mb_y, nb, rd, pf);
+    /* ---- from here on the loaded values are used */
+    L->neighbour = nb;
+    L->type_top = t_top; L->type_left = t_left; L->type_topright = t_tr; L->type_topleft = t_tl;
     PCAMV_WAVE_SYNC();
     FOR_CAND(i, 48) { L->cref[i] = -2; L->cmv[i][0] = 0; L->cmv[i][1] = 0; }
     PCAMV_WAVE_SYNC();
-    int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
-    int b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
-    int t4 = (4 * (mb_y - 1) + 3) * s4 + 4 * mb_x, t8 = (2 * (mb_y - 1) + 1) * s8 + 2 * mb_x;
-    /* the ten neighbouring 4x4 motion entries, one per lane: 0 top-left, 1..4 top, 5 top-right, 6..9 left */
     FOR_CAND(i, 10) {
-        int ok, c8, m4, r8;
-        if (i == 0) { ok = L->neighbour & NB_TOPLEFT; c8 = SCAN8_0 - 1 - 8; m4 = t4 - 1; r8 = t8 - 1; }
-        else if (i <= 4) { ok = L->neighbour & NB_TOP; c8 = SCAN8_0 - 8 + (i - 1); m4 = t4 + (i - 1); r8 = t8 + ((i - 1) >> 1); }
-        else if (i == 5) { ok = L->neighbour & NB_TOPRIGHT; c8 = SCAN8_0 + 4 - 8; m4 = t4 + 4; r8 = t8 + 2; }
-        else { ok = L->neighbour & NB_LEFT; c8 = SCAN8_0 - 1 + 8 * (i - 6); m4 = b4 - 1 + (i - 6) * s4; r8 = b8 - 1 + ((i - 6) >> 1) * s8; }
-        if (ok) { const uint32_t w_ = NB_LD32(&F.mv[2 * m4]); L->cref[c8] = NB_LD8(&F.ref8[r8]); L->cmv[c8][0] = (int16_t)(w_ & 0xffff); L->cmv[c8][1] = (int16_t)(w_ >> 16); }
+        const int c8 = nb_c8[NB_SLOT(i)];
+        if (c8 >= 0) { const uint32_t w_ = nb_w[NB_SLOT(i)]; L->cref[c8] = (int8_t)nb_r[NB_SLOT(i)]; L->cmv[c8][0] = (int16_t)(w_ & 0xffff); L->cmv[c8][1] = (int16_t)(w_ >> 16); }
     }
     PCAMV_WAVE_SYNC();
     int pm[2];
     predict_mv_pskip(L, pm);
     L->pskip_mv[0] = (int16_t)pm[0]; L->pskip_mv[1] = (int16_t)pm[1];
+    } else {
+    L->neighbour = 0;
+    L->type_left = L->type_top = L->type_topleft = L->type_topright = -1;
     }
 
     int fmv = 4 * F.mv_range;
@@ -157,8 +173,8 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
     L->mv_max_spel[1] = imin(L->mv_max_spel[1], fmv * 4);
     L->mv_min_fpel[1] = (L->mv_min_spel[1] >> 2) + 5;
     L->mv_max_fpel[1] = (L->mv_max_spel[1] >> 2) - 5;
-    prim_load_fenc(F, L);
-    if (rd && !lite) prim_rd_load(F, L);            /* --subme >= 6: intra neighbours, entropy-coder neighbourhood, context states */
+    if (lite) prim_load_fenc(F, L);
+    else prim_mb_fetch_store(F, L, rd, pf);         /* source pixels; --subme >= 6: intra neighbours, entropy-coder neighbourhood, context states */
 }
 
 /* ---------------------------------------------------------------- motion search */

@@ -17,53 +17,103 @@
 __device__ __forceinline__ uint32_t rep4(int v) { return (uint32_t)(v & 255) * 0x01010101u; }
 __device__ __forceinline__ int bsum4(uint32_t v) { return (int)__builtin_amdgcn_sad_u8(v, 0u, 0u); }
 
-/* neighbourhood of a macroblock for the RD decision: intra prediction borders (unfiltered pass-1 reconstruction of the
- * neighbours), entropy-coder context inputs (non-zero flags / counts, coded block patterns, MV differences), CABAC states */
-__device__ __forceinline__ void prim_rd_load(const FrameDev &F, MBLocal *L)
+/* Everything a macroblock needs from memory before its analysis can start, apart from the neighbours' motion (pcamv_logic.h
+ * mb_load): the source pixels and, for the RD decision, the intra prediction borders (unfiltered pass-1 reconstruction of the
+ * neighbours), the entropy coder's context inputs (non-zero flags / counts, coded block patterns, MV differences), the slice's
+ * CABAC states and the (bits, next state) table.  Two halves: prim_mb_fetch ISSUES every load into registers and uses none of
+ * them, prim_mb_fetch_store puts them into LDS -- so that all of it, together with the caller's own neighbour loads, is ONE
+ * memory round trip on the macroblock chain.  (One load + LDS store per role and branch used to be a dozen round trips in a row:
+ * a store needs its value, so every branch waited for its own load.) */
+struct MbFetch { uint32_t fy, fc, role, s0, s1, t0, t1, t2, t3; int b0, b1; };
+__device__ __forceinline__ void prim_mb_fetch(const FrameDev &F, int mb_x_, int mb_y_, int nb_, int rd_, MbFetch &P)
 {
-    PCAMV_WAVE_SYNC();
+    const int mb_x = rfl(mb_x_), mb_y = rfl(mb_y_), nb = rfl(nb_), rd = rfl(rd_);
     const int lane = LANE();
-    const int xy = L->mb_xy, top = xy - F.mb_w, nb = L->neighbour;
-    if (lane < 48) { L->nzc[lane] = 0; L->i4mode[lane] = -1; ((uint32_t *)L->cmvd)[lane] = 0; }
-    PCAMV_WAVE_SYNC();
+    const int xy = mb_y * F.mb_w + mb_x, top = xy - F.mb_w;
+    { const int row = lane >> 2, c4 = lane & 3;
+      P.fy = *(const uint32_t *)(F.fenc[0] + (size_t)(mb_y * 16 + row) * F.w + mb_x * 16 + c4 * 4); }
+    P.fc = 0;
+    if (lane < 32) {
+        const int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        P.fc = *(const uint32_t *)((plane ? F.fenc[2] : F.fenc[1]) + (size_t)(mb_y * 8 + row) * (F.w >> 1) + mb_x * 8 + c4 * 4);
+    }
+    P.role = 0; P.b0 = P.b1 = 0; P.s0 = P.s1 = P.t0 = P.t1 = P.t2 = P.t3 = 0;
+    if (!rd) return;
     if (lane < 16) {
         const int k = lane & 7, is_left = lane >> 3;
-        /* cache positions of the bottom row / right column entries: 4 luma, 2 Cb, 2 Cr */
-        const int pos = is_left ? (k < 4 ? 3 + 8 * (1 + k) : k < 6 ? 0 + 8 * (1 + (k - 4)) : 0 + 8 * (4 + (k - 6)))
-                                : (k < 4 ? 4 + k : k < 6 ? 1 + (k - 4) : 1 + (k - 6) + 3 * 8);
-        const int avail = is_left ? (nb & NB_LEFT) : (nb & NB_TOP);
-        uint8_t v = 0x80;
-        if (avail) v = (uint8_t)NB_LD8(&F.nb_nz[(is_left ? xy - 1 : top) * 16 + 8 * is_left + k]);
-        L->nzc[pos] = v;
+        P.role = 0x80;
+        if (is_left ? (nb & NB_LEFT) : (nb & NB_TOP)) P.role = (uint8_t)NB_LD8(&F.nb_nz[(is_left ? xy - 1 : top) * 16 + 8 * is_left + k]);
     } else if (lane < 24) {
-        const int k = lane - 16, is_left = k >> 2, j = k & 3;
-        const int avail = is_left ? (nb & NB_LEFT) : (nb & NB_TOP);
-        if (avail) {
-            const int pos = is_left ? SCAN8_0 - 1 + 8 * j : SCAN8_0 - 8 + j;
-            ((uint32_t *)L->cmvd)[pos] = NB_LD32(&F.nb_mvd[((is_left ? xy - 1 : top) * 8 + k) * 2]);
-            L->i4mode[pos] = 2;                                  /* inter neighbours count as DC (common/macroblock.c:1282) */
-        }
-    } else if (lane == 24) L->cbp_top = (nb & NB_TOP) ? (int)(int16_t)NB_LD16(&F.nb_cbp[top]) : -1;
-    else if (lane == 25) L->cbp_left = (nb & NB_LEFT) ? (int)(int16_t)NB_LD16(&F.nb_cbp[xy - 1]) : -1;
-    else if (lane == 26) L->b_fast_intra = xy > 4 && F.ref_is_inter;          /* analyse.c:363-378 */
+        const int k = lane - 16, is_left = k >> 2;
+        if (is_left ? (nb & NB_LEFT) : (nb & NB_TOP)) P.role = NB_LD32(&F.nb_mvd[((is_left ? xy - 1 : top) * 8 + k) * 2]);
+    } else if (lane == 24) { if (nb & NB_TOP) P.role = (uint32_t)(int)(int16_t)NB_LD16(&F.nb_cbp[top]); }
+    else if (lane == 25) { if (nb & NB_LEFT) P.role = (uint32_t)(int)(int16_t)NB_LD16(&F.nb_cbp[xy - 1]); }
     /* borders: luma 25 + 16, chroma 2 x (9 + 8) = 75 bytes, agent-scope loads (the neighbours stored them write-through) */
-    for (int i = lane; i < 75; i += 64) {
-        int c, is_left, k;
-        if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
-        else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
-        const int w = c ? 8 : 16, pw = c ? F.w >> 1 : F.w, x0 = L->mb_x * w, y0 = L->mb_y * w;
-        const uint8_t *pl = c == 0 ? F.rec[0] : c == 1 ? F.rec[1] : F.rec[2];
-        uint8_t v = 0;
-        if (is_left) { if (L->mb_x > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 + k) * pw + x0 - 1); L->ib_left[c][k] = v; }
-        else { if (L->mb_y > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 - 1) * pw + clip3i(x0 + k, 0, pw - 1)); L->ib_top[c][4 + k] = v; }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int i = lane + 64 * r;
+        int v = 0;
+        if (i < 75) {
+            int c, is_left, k;
+            if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
+            else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
+            const int w = c ? 8 : 16, pw = c ? F.w >> 1 : F.w, x0 = mb_x * w, y0 = mb_y * w;
+            const uint8_t *pl = c == 0 ? F.rec[0] : c == 1 ? F.rec[1] : F.rec[2];
+            if (is_left) { if (mb_x > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 + k) * pw + x0 - 1); }
+            else if (mb_y > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 - 1) * pw + clip3i(x0 + k, 0, pw - 1));
+        }
+        if (r == 0) P.b0 = v; else P.b1 = v;
     }
     if (F.b_cabac) {
         const uint32_t *src = (const uint32_t *)(xy == 0 ? F.cabac_init : F.cabac);
-        uint32_t *dst = (uint32_t *)L_CAB(L, 0);
-        if (xy == 0) { dst[lane] = src[lane]; if (lane < 52) dst[64 + lane] = src[64 + lane]; }
-        else { dst[lane] = NB_LD32(src + lane); if (lane < 52) dst[64 + lane] = NB_LD32(src + 64 + lane); }
+        if (xy == 0) { P.s0 = src[lane]; if (lane < 52) P.s1 = src[64 + lane]; }
+        else { P.s0 = NB_LD32(src + lane); if (lane < 52) P.s1 = NB_LD32(src + 64 + lane); }
+        P.t0 = F.cabac_tab[lane]; P.t1 = F.cabac_tab[64 + lane]; P.t2 = F.cabac_tab[128 + lane]; P.t3 = F.cabac_tab[192 + lane];
+    }
+}
+__device__ __forceinline__ void prim_mb_fetch_store(const FrameDev &F, MBLocal *L, int rd_, const MbFetch &P)
+{
+    const int rd = rfl(rd_);
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    { const int row = lane >> 2, c4 = lane & 3; sts4(L->fenc + row * 16 + c4 * 4, P.fy); }
+    if (lane < 32) { const int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1; sts4(L->fenc + 256 + row * 16 + plane * 8 + c4 * 4, P.fc); }
+    if (rd) {
+        const int xy = L->mb_xy, nb = L->neighbour;
+        if (lane < 48) { L->nzc[lane] = 0; L->i4mode[lane] = -1; ((uint32_t *)L->cmvd)[lane] = 0; }
+        PCAMV_WAVE_SYNC();
+        if (lane < 16) {
+            const int k = lane & 7, is_left = lane >> 3;
+            /* cache positions of the bottom row / right column entries: 4 luma, 2 Cb, 2 Cr */
+            const int pos = is_left ? (k < 4 ? 3 + 8 * (1 + k) : k < 6 ? 0 + 8 * (1 + (k - 4)) : 0 + 8 * (4 + (k - 6)))
+                                    : (k < 4 ? 4 + k : k < 6 ? 1 + (k - 4) : 1 + (k - 6) + 3 * 8);
+            L->nzc[pos] = (uint8_t)P.role;
+        } else if (lane < 24) {
+            const int k = lane - 16, is_left = k >> 2, j = k & 3;
+            if (is_left ? (nb & NB_LEFT) : (nb & NB_TOP)) {
+                const int pos = is_left ? SCAN8_0 - 1 + 8 * j : SCAN8_0 - 8 + j;
+                ((uint32_t *)L->cmvd)[pos] = P.role;
+                L->i4mode[pos] = 2;                                  /* inter neighbours count as DC (common/macroblock.c:1282) */
+            }
+        } else if (lane == 24) L->cbp_top = (nb & NB_TOP) ? (int)P.role : -1;
+        else if (lane == 25) L->cbp_left = (nb & NB_LEFT) ? (int)P.role : -1;
+        else if (lane == 26) L->b_fast_intra = xy > 4 && F.ref_is_inter;          /* analyse.c:363-378 */
 #pragma unroll
-        for (int k = 0; k < 4; k++) L_CTAB(L)[64 * k + lane] = F.cabac_tab[64 * k + lane];
+        for (int r = 0; r < 2; r++) {
+            const int i = lane + 64 * r;
+            if (i < 75) {
+                int c, is_left, k;
+                if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
+                else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
+                const uint8_t v = (uint8_t)(r == 0 ? P.b0 : P.b1);
+                if (is_left) L->ib_left[c][k] = v; else L->ib_top[c][4 + k] = v;
+            }
+        }
+        if (F.b_cabac) {
+            uint32_t *dst = (uint32_t *)L_CAB(L, 0);
+            dst[lane] = P.s0; if (lane < 52) dst[64 + lane] = P.s1;
+            L_CTAB(L)[lane] = P.t0; L_CTAB(L)[64 + lane] = P.t1; L_CTAB(L)[128 + lane] = P.t2; L_CTAB(L)[192 + lane] = P.t3;
+        }
     }
     PCAMV_WAVE_SYNC();
 }
