@@ -365,6 +365,22 @@ def main():
             sub.close()
         sweep.append({"gops": G, "value": value, "unit": "MB/s", "ms_per_step": dt / args.steps * 1e3})
         out["g_sweep"] = sweep
+        # round 1's workload (--subme 5: no RD decision, a frame is a wavefront of macroblocks instead of one chain) for comparison
+        if args.subme >= 6 and not args.no_cabac:
+            p5 = pcamv_amd.param_default(W, H)
+            pcamv_amd.param_parse(p5, "me", args.me)
+            pcamv_amd.param_parse(p5, "subme", 5)
+            sub = Gops(pcamv_amd, p5, dframes, range(256), local, closed_loop)
+            for t in range(2):
+                sub.step(t, args.qp, args.emrate, stream.cuda_stream)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for t in range(5):
+                sub.step(2 + t, args.qp, args.emrate, stream.cuda_stream)
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - ts) / 5
+            out["other_workloads"] = [{"workload": f"{W}x{H} --me {args.me} --subme 5, 256 GOPs in flight, same closed loop", "value": 256 * n_mb / d, "unit": "MB/s", "ms_per_step": d * 1e3}]
+            sub.close()
 
     # ---- CPU baseline (rank 0, N=1): the port on a bounded sample of the same 1080p workload; the reference itself on CIF
     if solo and args.cpu_frames > 0:
