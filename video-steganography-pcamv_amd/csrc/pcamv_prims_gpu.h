@@ -190,23 +190,14 @@ __device__ __forceinline__ void prim_win_load(const FrameDev &F, MBLocal *L, int
     const int cx0 = L->mb_x * 8 + PCAMV_CPAD + ((bmx - 3) >> 3), cy0 = L->mb_y * 8 + PCAMV_CPAD + ((bmy - 3) >> 3);
     const gp8 lb = (gp8)F.luma_base, cb = (gp8)F.chroma_base[0];
     const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size, cstride = (uint32_t)F.cstride, cps = (uint32_t)F.cplane_size;
-    /* all ten dwords of a lane are requested before the first is stored: one memory round trip for the window */
-    constexpr int NL = 4 * WIN_LH * (WIN_LW / 4), NC = 2 * WIN_CH * (WIN_CW / 4), KL = (NL + 63) / 64, KC = (NC + 63) / 64;
-    uint32_t tl[KL], tc[KC];
-#pragma unroll
-    for (int k = 0; k < KL; k++) {
-        const int i = lane + 64 * k, pl = i / (WIN_LH * (WIN_LW / 4)), r = (i / (WIN_LW / 4)) % WIN_LH, c = i % (WIN_LW / 4);
-        tl[k] = i < NL ? gld4(lb, (uint32_t)pl * psz + (uint32_t)(y0 + r) * stride + (uint32_t)(x0 + 4 * c)) : 0u;
+    for (int i = lane; i < 4 * WIN_LH * (WIN_LW / 4); i += 64) {
+        const int pl = i / (WIN_LH * (WIN_LW / 4)), r = (i / (WIN_LW / 4)) % WIN_LH, c = i % (WIN_LW / 4);
+        L->win[i] = gld4(lb, (uint32_t)pl * psz + (uint32_t)(y0 + r) * stride + (uint32_t)(x0 + 4 * c));
     }
-#pragma unroll
-    for (int k = 0; k < KC; k++) {
-        const int i = lane + 64 * k, pl = i / (WIN_CH * (WIN_CW / 4)), r = (i / (WIN_CW / 4)) % WIN_CH, c = i % (WIN_CW / 4);
-        tc[k] = i < NC ? gld4(cb, (uint32_t)pl * cps + (uint32_t)(cy0 + r) * cstride + (uint32_t)(cx0 + 4 * c)) : 0u;
+    for (int i = lane; i < 2 * WIN_CH * (WIN_CW / 4); i += 64) {
+        const int pl = i / (WIN_CH * (WIN_CW / 4)), r = (i / (WIN_CW / 4)) % WIN_CH, c = i % (WIN_CW / 4);
+        L->win[4 * WIN_LP / 4 + i] = gld4(cb, (uint32_t)pl * cps + (uint32_t)(cy0 + r) * cstride + (uint32_t)(cx0 + 4 * c));
     }
-#pragma unroll
-    for (int k = 0; k < KL; k++) if (lane + 64 * k < NL) L->win[lane + 64 * k] = tl[k];
-#pragma unroll
-    for (int k = 0; k < KC; k++) if (lane + 64 * k < NC) L->win[4 * WIN_LP / 4 + lane + 64 * k] = tc[k];
     if (lane == 0) { L->win_x0 = x0; L->win_y0 = y0; L->win_cx0 = cx0; L->win_cy0 = cy0; }
     PCAMV_WAVE_SYNC();
 }
@@ -641,36 +632,31 @@ __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L, i
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    /* luma and chroma fetches are both issued before either is stored: one memory round trip per prediction, not two */
-    const int row = lane >> 2, c4 = lane & 3;
-    uint32_t v;
-    {
-        const int i8 = SCAN8_0 + c4 + 8 * (row >> 2);
-        const int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+    { int row = lane >> 2, c4 = lane & 3, i8 = SCAN8_0 + c4 + 8 * (row >> 2);
+      int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+      uint32_t v;
+      if (win) {
+          const int dx = mvx & 3, dy = mvy & 3;
+          const int wb = (L->mb_y * 16 + row + PCAMV_PAD + (mvy >> 2) - L->win_y0) * WIN_LW + (L->mb_x * 16 + 4 * c4 + PCAMV_PAD + (mvx >> 2) - L->win_x0);
+          v = wld4(L, wb + ((dx != 0) + 2 * (dy == 2)) * WIN_LP + (dy == 3 ? WIN_LW : 0));
+          if ((dx | dy) & 1) v = avg4(v, wld4(L, wb + (dy ? (2 + (dx == 2)) * WIN_LP : 0) + (dx == 3)));
+      } else v = luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
+      sts4(L->pred + row * 16 + 4 * c4, v); }
+    {   /* chroma: every lane two pixels (one 2x2 chroma block row carries one luma 4x4's MV) */
+        int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3;
+        int i8 = SCAN8_0 + c2 + 8 * (row >> 1);
+        int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
+        uint32_t t;
         if (win) {
-            const int dx = mvx & 3, dy = mvy & 3;
-            const int wb = (L->mb_y * 16 + row + PCAMV_PAD + (mvy >> 2) - L->win_y0) * WIN_LW + (L->mb_x * 16 + 4 * c4 + PCAMV_PAD + (mvx >> 2) - L->win_x0);
-            v = wld4(L, wb + ((dx != 0) + 2 * (dy == 2)) * WIN_LP + (dy == 3 ? WIN_LW : 0));
-            if ((dx | dy) & 1) v = avg4(v, wld4(L, wb + (dy ? (2 + (dx == 2)) * WIN_LP : 0) + (dx == 3)));
-        } else v = luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
-    }
-    /* chroma: every lane two pixels (one 2x2 chroma block row carries one luma 4x4's MV) */
-    const int plane = lane >> 5, crow = (lane & 31) >> 2, c2 = lane & 3;
-    uint32_t t;
-    {
-        const int i8 = SCAN8_0 + c2 + 8 * (crow >> 1);
-        const int mvx = clip3i(L->cmv[i8][0], L->mv_min[0], L->mv_max[0]), mvy = clip3i(L->cmv[i8][1], L->mv_min[1], L->mv_max[1]);
-        if (win) {
-            const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + crow + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
+            const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + row + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
             const int dx = mvx & 7, dy = mvy & 7;
             const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
             const uint32_t a = wld4(L, b), bb = wld4(L, b + WIN_CW);
             t = (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x05040100u), W, 32u, false) >> 6)
               | (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x06050201u), W, 32u, false) >> 6) << 8;
-        } else t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + crow, mvx, mvy);
+        } else t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
+        *(uint16_t *)(L->pred + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
     }
-    sts4(L->pred + row * 16 + 4 * c4, v);
-    *(uint16_t *)(L->pred + 256 + crow * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
     PCAMV_WAVE_SYNC();
 }
 /* which: 0 luma only, 1 luma+chroma, 2 chroma only; (mvx,mvy) already clipped */
@@ -678,12 +664,12 @@ __device__ __forceinline__ void prim_predict_16x16(const FrameDev &F, MBLocal *L
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    const int row = lane >> 2, c4 = lane & 3, plane = lane >> 5, crow = (lane & 31) >> 2, c2 = lane & 3;
-    uint32_t v = 0, t = 0;                           /* both fetches issued before either store: one round trip */
-    if (which != 2) v = luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy);
-    if (which != 0) t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + crow, mvx, mvy);
-    if (which != 2) sts4(L->pred + row * 16 + 4 * c4, v);
-    if (which != 0) *(uint16_t *)(L->pred + 256 + crow * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
+    if (which != 2) { int row = lane >> 2, c4 = lane & 3; sts4(L->pred + row * 16 + 4 * c4, luma_row4(F, L->mb_x * 16 + 4 * c4, L->mb_y * 16 + row, mvx, mvy)); }
+    if (which != 0) {
+        int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3;
+        uint32_t t = chroma_px2(F, plane, L->mb_x * 8 + 2 * c2, L->mb_y * 8 + row, mvx, mvy);
+        *(uint16_t *)(L->pred + 256 + row * 16 + plane * 8 + 2 * c2) = (uint16_t)t;
+    }
     PCAMV_WAVE_SYNC();
 }
 
