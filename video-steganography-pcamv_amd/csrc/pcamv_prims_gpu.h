@@ -248,6 +248,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
     PCAMV_WAVE_SYNC();
     const unsigned long long t_ev = PROF_T();
     PROF_CNT(32, 1); PROF_CNT(33, n);
+    int key_acc = 0x7fffffff;
     {
         const int slot = lane >> lgn, blk = lane & (nblk - 1);
         const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
@@ -303,6 +304,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
             v = group_sum(v, nblk);
             if (!(flags & EV_NOMV)) v += (int)cost_tab[(uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)] + (int)cost_tab[(uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)];
             if (blk == 0 && c < n) L->ccost[c] = act ? v : PCAMV_COST_MAX;
+            if (blk == 0 && act) key_acc = imin(key_acc, (v << 6) | c);
         }
     }
     PCAMV_WAVE_SYNC();
@@ -346,8 +348,11 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
         }
     }
     PCAMV_WAVE_SYNC();
+    /* without a chroma term the totals are still in the registers of the lanes that formed them: the smallest (cost, index) comes
+     * straight out of those (the costs go to LDS for the control code that reads single ones, but nothing waits for that) */
     int key = 0x7fffffff;
-    if (lane < n) { int cc = L->ccost[lane]; if (cc < PCAMV_COST_MAX) key = (cc << 6) | lane; }
+    if ((flags & EV_CHROMA) && ip <= PIX_8x8) { if (lane < n) { int cc = L->ccost[lane]; if (cc < PCAMV_COST_MAX) key = (cc << 6) | lane; } }
+    else key = key_acc;
     key = wave_min_i32(key);
     EvalRes res;
     if (key == 0x7fffffff) { res.cost = PCAMV_COST_MAX; res.idx = -1; }
