@@ -96,3 +96,30 @@ def test_live_against_the_reference_coder():
                 for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
                     assert np.array_equal(mbs[a], got[b]), (W, H, me, cabac, t, a)
                 ref, prev = rec, helpers.mv_field(mbs["mv"], W // 16, H // 16)
+
+
+def test_parsers_survive_arbitrary_input():
+    """the extractor takes bytes from outside: random strings and randomly damaged real slices must come back as an error or as
+    some motion field, never as a crash or a hang (every loop of the parsers is bounded, every read is checked against the end)"""
+    import pcamv_amd
+    rng = np.random.default_rng(2024)
+    real = {True: helpers.load("pslice_qcif_hex_subme6_qp34")["slice_data"].tobytes(), False: helpers.load("pslice_cavlc_qcif_hex_subme6_qp34")["slice_data"].tobytes()}
+    outcomes = {"ok": 0, "error": 0}
+    for k in range(300):
+        cabac = bool(k & 1)
+        if k % 3 == 0:
+            data = rng.integers(0, 256, int(rng.integers(1, 4000)), dtype=np.uint8).tobytes()
+        else:
+            d = bytearray(real[cabac])
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(0, len(d)))] ^= int(rng.integers(1, 256))
+            if k % 5 == 0:
+                d = d[:int(rng.integers(1, len(d)))]
+            data = bytes(d)
+        try:
+            got = pcamv_amd.parse_pslice_cabac(data, 11, 9, int(rng.integers(0, 52))) if cabac else pcamv_amd.parse_pslice_cavlc(data, 11, 9)
+            assert len(got) == 99
+            outcomes["ok"] += 1
+        except pcamv_amd.PcamvError:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 100, outcomes
