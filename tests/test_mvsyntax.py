@@ -123,3 +123,29 @@ def test_parsers_survive_arbitrary_input():
         except pcamv_amd.PcamvError:
             outcomes["error"] += 1
     assert outcomes["error"] > 100, outcomes
+
+
+def test_parsers_under_sanitizers(tmp_path):
+    """the same parsers compiled for the CPU with -fsanitize=address,undefined (tests/fuzz/fuzz_mvsyntax.cpp): damaged real slices
+    in exact-size heap buffers; any out-of-bounds read, overflow or undefined shift aborts the run"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_mvsyntax")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I", os.path.join(ROOT, "video-steganography-pcamv_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "fuzz", "fuzz_mvsyntax.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode and "asan" in (r.stderr or "").lower() and "cannot find" in r.stderr:
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    args = [exe, "1500"]
+    for name in ("pslice_qcif_hex_subme6_qp34", "pslice_cavlc_qcif_hex_subme6_qp34", "pslice_cif_dia_subme4_p4x4_qp16", "pslice_cavlc_cif_hex_subme5_p4x4_qp10"):
+        g = helpers.load(name)
+        f = tmp_path / (name + ".bin")
+        f.write_bytes(g["slice_data"].tobytes())
+        args += [str(f), str(int(g["width"]) // 16), str(int(g["height"]) // 16), str(int(g["qp"])), str(int(g["cabac"]) if "cabac" in g else 1)]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert "err" in r.stdout
