@@ -204,8 +204,9 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         if ((size_t)waves > total) waves = (long)total;
         /* the second pass can take `unit` macroblocks of a row per task (PCAMV_PASS2_UNIT; the dependency graph is the
          * same on the coarser grid).  Measured at G=256: 115.1 / 114.7 / 116.9 / 122.6 ms per step for 1 / 2 / 4 / 8 --
-         * its queue traffic is not what bounds it any more; default 1.  Same buffers: the two kernels never overlap. */
-        { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : 1;
+         * its queue traffic is not what bounds it any more.  With thousands of GOPs in flight it is again: 4096 GOPs 2300 / 2277 /
+         * 2264 / 2253 ms per step.  Default: 8 from 1024 GOPs on, else 1.  Same buffers: the two kernels never overlap. */
+        { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : (n >= 1024 ? 8 : 1);
           b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.raster = 0; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
           b->fl2.total = (unsigned)n * (unsigned)b->fl2.n_mb;
           unsigned qb2 = 0;
