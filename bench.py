@@ -202,7 +202,8 @@ def main():
                  "rd trial: cabac residual", "rd: final encode + entropy commit", "-",
                  "residual: per-block data", "residual: coded_block_flag chains", "residual: maps + levels", "COUNT residual walks", "COUNT blocks with levels",
                  "COUNT coded blocks", "COUNT non-zero levels", "-",
-                 "COUNT list evaluations", "COUNT candidates", "-", "-", "-", "-", "list evaluation (cycles)"]
+                 "COUNT list evaluations", "COUNT candidates", "rca: copy + window load", "rca: first nine-point list", "rca: 4 predictions + transforms", "rca: 36-candidate list", "list evaluation (cycles)",
+                 "-", "COUNT rca groups of 4", "COUNT rca single re-encodes", "COUNT carriers"]
         print("wave cycles per macroblock:", {names[i]: round(prof[i] / nmb) for i in range(len(names)) if names[i] != "-"}, file=sys.stderr)
 
     # dominant kernel: average duration of one launch, HIP events on its own stream, over the timed steps

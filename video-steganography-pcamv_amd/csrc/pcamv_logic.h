@@ -984,7 +984,9 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
     int cost = 0, min_cost;
     int b_1_neighbor = 0, b_error_pos = 0;
     if (!have_base) { update_cache(L, a); mb_encode(F, L); prim_copy_pred(L, L->recb0); }
+    const unsigned long long t_n = PROF_T();
     min_cost = rca_nine(F, L, me, L->recb0, bmx, bmy, 1, &cost, win);
+    PROF_ADD(35, t_n);
     me->cost_rec = L->nbc[8];
     const int want_optimal = !(min_cost < me->cost_rec);
     min_cost = PCAMV_COST_MAX; *m_x = 0; *m_y = 0;
@@ -996,13 +998,18 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
          * neighbour k; groups: ii = 0..3 always, 4..7 and 8..11 only when none of 0..3 qualified */
         const int flags = (F.subme > 1 ? EV_SATD : 0) | (F.b_chroma_me ? EV_CHROMA : 0) | EV_WIN | EV_SRC4;
         for (int grp = 0; grp < 3; grp++) {
+            PROF_CNT(40, 1);
+            const unsigned long long t_g = PROF_T();
             for (int j = 0; j < 4; j++) prim_predict_win16(F, L, j, bmx + d_mv_x(4 * grp + j), bmy + d_mv_y(4 * grp + j));
             prim_mb_transform4(F, L);
+            PROF_ADD(36, t_g);
+            const unsigned long long t_l = PROF_T();
             FOR_CAND(c, 36) {
                 int k = c >> 2, ii = 4 * grp + (c & 3);
                 L->cxy[c] = CAND_PACK(bmx + d_mv_x(ii) + d_nb_x(k), bmy + d_mv_y(ii) + d_nb_y(k));
             }
             eval_cands(F, L, me, L->pred4[0], 36, flags);
+            PROF_ADD(37, t_l);
             for (int j = 0; j < 4; j++) {
                 const int ii = 4 * grp + j;
                 int min1 = PCAMV_COST_MAX;
@@ -1015,6 +1022,7 @@ PCAMV_DEV int rca_mv_cost(const FrameDev &F, MBLocal *L, Analysis *a, MEState *m
         }
     } else
     for (int ii = 0; ii < 12; ii++) {
+        PROF_CNT(41, 1);
         int bx1 = bmx + d_mv_x(ii), by1 = bmy + d_mv_y(ii);
         me->mv[0] = bx1; me->mv[1] = by1;
         update_cache(L, a); mb_encode(F, L, win); prim_copy_pred(L, L->recb);

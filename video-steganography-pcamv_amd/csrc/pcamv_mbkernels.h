@@ -147,6 +147,8 @@ PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, i
 {
     int *slots = L->slots;
     if (F.rec_mb[xy].used && n > 0) {
+        const unsigned long long t_w = PROF_T();
+        PROF_CNT(42, n);
         prim_copy_pred(L, L->recb0);
         /* a 16x16 macroblock whose RCA neighbourhood (+-3 quarter pels) needs no MV clipping reads its
          * reference pixels from an LDS window loaded once, instead of ~30 scattered global fetches */
@@ -155,6 +157,7 @@ PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, i
             const int bx = a->me16x16.mv[0], by = a->me16x16.mv[1];
             if (bx - 3 >= L->mv_min[0] && bx + 3 <= L->mv_max[0] && by - 3 >= L->mv_min[1] && by + 3 <= L->mv_max[1]) { prim_win_load(F, L, bx, by); win = 1; }
         }
+        PROF_ADD(34, t_w);
         for (int k = 0; k < n; k++) {
             MEState *me = slot_me(L, a, slots[k]);
             int dx = 0, dy = 0;
