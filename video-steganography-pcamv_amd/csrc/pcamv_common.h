@@ -28,6 +28,17 @@
 
 #define PCAMV_PAD 32
 #define PCAMV_CPAD 16
+/* Luma reference planes in HBM are stored as vertical STRIPS: strip s holds the padded-plane columns 28 s .. 28 s + 31 (its last
+ * four are the next strip's first four again), row after row with a pitch of 32 bytes, strips one after the other:
+ *     byte(x, y) = s * 32 * lines + y * 32 + (x - 28 s),   s = x / 28.
+ * A 128-byte cache line is 32 x 4 pixels instead of 128 x 1: the 48 x 48 window of a search is ~34 lines instead of ~66, the
+ * 24 x 20 neighbourhood of a sub-pel refinement ~10 instead of ~24 per plane.  Thanks to the four repeated columns an (unaligned)
+ * 4-byte fetch at any x never straddles two strips, a row step is +32 whatever the picture size (scalar row bases), and x + 1
+ * needs no second look-up.  Writer: k_hpel (groups of 4 pixels are aligned with the strips: 28 = 7 x 4).  Chroma planes stay raster. */
+#define PCAMV_LSW 28
+#define PCAMV_LROW 32
+#define PCAMV_LSTRIPS(stride) (((stride) + PCAMV_LSW - 1) / PCAMV_LSW + 1)
+#define PCAMV_LSTRIP_OF(x) (((uint32_t)(x) * 18725u) >> 19)          /* x / 28 for x < 40000 */
 #define PCAMV_COST_MAX (1 << 28)
 #define PCAMV_COST_MV_LEN (4 * 4 * 2048 + 1)
 #define PCAMV_COST_MV_CENTRE (2 * 4 * 2048)
@@ -39,12 +50,12 @@ enum { PIX_16x16, PIX_16x8, PIX_8x16, PIX_8x8, PIX_8x4, PIX_4x8, PIX_4x4 };
 struct FrameDev {
     int w, h, mb_w, mb_h, n_mb;
     int stride, lines, cstride, clines;
-    long long plane_size;          /* stride*lines: the four luma planes are contiguous, plane k = luma[0] + k*plane_size */
+    long long plane_size;          /* strips * 32 * lines: the four luma planes are contiguous, plane k = luma_base + k*plane_size */
+    int lskip;                     /* 32 * lines - 28: byte(x, y) = y * 32 + x + (x / 28) * lskip */
     long long cplane_size;         /* the two chroma planes are contiguous too: chroma_base[1] = chroma_base[0] + cplane_size */
     const uint8_t *fenc[3];
     const uint8_t *raw[3];         /* un-padded reference planes the plane-production kernels read */
     uint8_t *luma_base, *chroma_base[2];   /* start of the padded allocations */
-    uint8_t *luma[4];              /* picture-origin pointers into the padded planes */
     uint8_t *chroma[2];
     uint8_t *rec[3];               /* pass-1 reconstruction out, tightly packed */
     int8_t *mb_type;

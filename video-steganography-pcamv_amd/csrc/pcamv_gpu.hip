@@ -300,13 +300,14 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     FrameDev &F = c->F;
     pcamv_frame_set_params(&F, p);
-    const size_t ysz = (size_t)F.w * F.h, lsz = (size_t)F.stride * F.lines, csz = (size_t)F.cstride * F.clines;
+    const size_t ysz = (size_t)F.w * F.h, lsz = (size_t)F.plane_size, csz = (size_t)F.cstride * F.clines;
     for (int i = 0; i < 3; i++) {
         HIPCHK(c, dalloc(&c->d_fenc[i], i ? ysz / 4 : ysz));
         HIPCHK(c, dalloc(&c->d_raw[i], i ? ysz / 4 : ysz));
         HIPCHK(c, dalloc(&c->d_rec[i], i ? ysz / 4 : ysz));
     }
     HIPCHK(c, dalloc(&c->d_luma, 4 * lsz + 64));
+    HIPCHK(c, hipMemset(c->d_luma, 0, 4 * lsz + 64));      /* the repeated columns of each plane's last strip are never written */
     HIPCHK(c, dalloc(&c->d_chroma[0], 2 * (csz + 64))); c->d_chroma[1] = c->d_chroma[0] + csz + 64;   /* one allocation: 32-bit offsets reach both */
     F.cplane_size = (long long)(csz + 64);
     HIPCHK(c, dalloc(&c->d_mb_type, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_ref8, (size_t)F.n_mb * 4)); HIPCHK(c, dalloc(&c->d_prev_ref, (size_t)F.n_mb * 4));
@@ -341,7 +342,6 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     long long lcg = 1; HIPCHK(c, hipMemcpy(c->d_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
     for (int i = 0; i < 3; i++) { F.fenc[i] = c->d_fenc[i]; F.rec[i] = c->d_rec[i]; F.raw[i] = c->d_raw[i]; }
     F.luma_base = c->d_luma; F.chroma_base[0] = c->d_chroma[0]; F.chroma_base[1] = c->d_chroma[1];
-    for (int k = 0; k < 4; k++) F.luma[k] = c->d_luma + k * lsz + (size_t)F.stride * PCAMV_PAD + PCAMV_PAD;
     for (int k = 0; k < 2; k++) F.chroma[k] = c->d_chroma[k] + (size_t)F.cstride * PCAMV_CPAD + PCAMV_CPAD;
     F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
     F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
@@ -597,7 +597,17 @@ extern "C" int pcamv_gpu_get_ref_planes(pcamv_ctx_t *c, uint8_t *out, int *strid
     if (!c || !out) return PCAMV_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(out, c->d_luma, 4 * (size_t)c->F.stride * c->F.lines, hipMemcpyDeviceToHost));
+    /* the device keeps the planes in strips (pcamv_common.h); the caller gets x264's raster planes */
+    const size_t psz = (size_t)c->F.plane_size;
+    uint8_t *tmp = (uint8_t *)malloc(4 * psz);
+    if (!tmp) return fail(c, PCAMV_EHIP, "out of host memory");
+    hipError_t e = hipMemcpy(tmp, c->d_luma, 4 * psz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(tmp); HIPCHK(c, e); }
+    for (int k = 0; k < 4; k++)
+        for (int y = 0; y < c->F.lines; y++)
+            for (int x = 0; x < c->F.stride; x++)
+                out[((size_t)k * c->F.lines + y) * c->F.stride + x] = tmp[k * psz + (size_t)y * PCAMV_LROW + x + (size_t)(x / PCAMV_LSW) * c->F.lskip];
+    free(tmp);
     if (stride) *stride = c->F.stride;
     if (lines) *lines = c->F.lines;
     return 0;

@@ -100,7 +100,8 @@ static inline void pcamv_frame_set_params(FrameDev *F, const pcamv_params_t *p)
     F->w = p->i_width; F->h = p->i_height; F->mb_w = F->w / 16; F->mb_h = F->h / 16; F->n_mb = F->mb_w * F->mb_h;
     F->stride = (F->w + 2 * PCAMV_PAD + 15) & ~15; F->lines = F->h + 2 * PCAMV_PAD;
     F->cstride = (F->w / 2 + 2 * PCAMV_CPAD + 15) & ~15; F->clines = F->h / 2 + 2 * PCAMV_CPAD;
-    F->plane_size = (long long)F->stride * F->lines;
+    F->plane_size = (long long)PCAMV_LSTRIPS(F->stride) * PCAMV_LROW * F->lines;   /* strip layout, pcamv_common.h */
+    F->lskip = PCAMV_LROW * F->lines - PCAMV_LSW;
     F->me_method = p->i_me_method; F->me_range = p->i_me_range; F->subme = p->i_subpel_refine; F->mv_range = p->i_mv_range;
     F->b_chroma_me = p->b_chroma_me && p->i_subpel_refine >= 5;     /* analyse.c:246-247 */
     F->b_fast_pskip = p->b_fast_pskip; F->b_dct_decimate = p->b_dct_decimate; F->b_cabac = p->b_cabac;

@@ -87,7 +87,10 @@ static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__re
     const int gx = x0 - PCAMV_PAD, eg0 = clip3i(gx, -4, W);
     const int rep = gx < -4 ? 0 : gx > W ? 3 : -1;
     const bool fast = eg0 >= 4 && eg0 + 8 <= W && ((uintptr_t)src & 3) == 0;
-    const size_t psz = (size_t)stride * lines;
+    const size_t psz = (size_t)F.plane_size;
+    const unsigned strip = PCAMV_LSTRIP_OF(x0);
+    const size_t strip_o = (size_t)x0 + (size_t)strip * (size_t)F.lskip;
+    const bool dup = strip > 0 && (unsigned)x0 == strip * PCAMV_LSW;
     uint32_t w[6][3];
     uint32_t of = 0, oh = 0, ov = 0, oc = 0;
     int ey_prev = 0;
@@ -128,11 +131,20 @@ static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__re
                 ov = (ov >> sh & 255) * 0x01010101u; oc = (oc >> sh & 255) * 0x01010101u;
             }
         }
-        const size_t o = (size_t)y * stride + x0;
+        /* strip layout (pcamv_common.h): the group's place in its own strip and, for a strip's first group, the repeat at the end
+         * of the strip before it */
+        const size_t o = (size_t)y * PCAMV_LROW + strip_o;
         *(uint32_t *)(planes + o) = of;
         *(uint32_t *)(planes + psz + o) = oh;
         *(uint32_t *)(planes + 2 * psz + o) = ov;
         *(uint32_t *)(planes + 3 * psz + o) = oc;
+        if (dup) {
+            const size_t o2 = o - (size_t)F.lskip;
+            *(uint32_t *)(planes + o2) = of;
+            *(uint32_t *)(planes + psz + o2) = oh;
+            *(uint32_t *)(planes + 2 * psz + o2) = ov;
+            *(uint32_t *)(planes + 3 * psz + o2) = oc;
+        }
     }
 }
 

@@ -96,6 +96,9 @@ typedef uint64_t __attribute__((aligned(1))) u64u;
 typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t gld4(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u32u *)(base + off); }
 __device__ __forceinline__ uint64_t gld8(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u64u *)(base + off); }
+/* luma planes are strips (pcamv_common.h): the x part of a pixel's byte offset; the y part is y * PCAMV_LROW.  4 bytes from there
+ * (and from x + 1: the repeated columns) lie in one strip */
+__device__ __forceinline__ uint32_t lsw_x(uint32_t x, uint32_t lskip) { return __umul24(PCAMV_LSTRIP_OF(x), lskip) + x; }
 __device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
 __device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
 
@@ -189,10 +192,10 @@ __device__ __forceinline__ void prim_win_load(const FrameDev &F, MBLocal *L, int
     const int x0 = L->mb_x * 16 + PCAMV_PAD + ((bmx - 3) >> 2), y0 = L->mb_y * 16 + PCAMV_PAD + ((bmy - 3) >> 2);
     const int cx0 = L->mb_x * 8 + PCAMV_CPAD + ((bmx - 3) >> 3), cy0 = L->mb_y * 8 + PCAMV_CPAD + ((bmy - 3) >> 3);
     const gp8 lb = (gp8)F.luma_base, cb = (gp8)F.chroma_base[0];
-    const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size, cstride = (uint32_t)F.cstride, cps = (uint32_t)F.cplane_size;
+    const uint32_t lskip = (uint32_t)F.lskip, psz = (uint32_t)F.plane_size, cstride = (uint32_t)F.cstride, cps = (uint32_t)F.cplane_size;
     for (int i = lane; i < 4 * WIN_LH * (WIN_LW / 4); i += 64) {
         const int pl = i / (WIN_LH * (WIN_LW / 4)), r = (i / (WIN_LW / 4)) % WIN_LH, c = i % (WIN_LW / 4);
-        L->win[i] = gld4(lb, (uint32_t)pl * psz + (uint32_t)(y0 + r) * stride + (uint32_t)(x0 + 4 * c));
+        L->win[i] = gld4(lb, (uint32_t)pl * psz + (uint32_t)(y0 + r) * PCAMV_LROW + lsw_x((uint32_t)(x0 + 4 * c), lskip));
     }
     for (int i = lane; i < 2 * WIN_CH * (WIN_CW / 4); i += 64) {
         const int pl = i / (WIN_CH * (WIN_CW / 4)), r = (i / (WIN_CW / 4)) % WIN_CH, c = i % (WIN_CW / 4);
@@ -236,7 +239,7 @@ __device__ __forceinline__ void chroma_block4_win(const MBLocal *L, int b, int m
  *           candidates per pass, group totals added to ccost[c] with an LDS atomic;
  *   result: lane c reads ccost[c], key = cost << 6 | c, wave minimum -> smallest cost, first index. */
 /* what a list evaluation reads of the frame descriptor */
-struct EvalEnv { const int16_t *cost_mv; const uint8_t *luma_base, *chroma_base; long long plane_size, cplane_size; int stride, cstride; int *trace; int trace_mb; };
+struct EvalEnv { const int16_t *cost_mv; const uint8_t *luma_base, *chroma_base; long long plane_size, cplane_size; int lskip, cstride; int *trace; int trace_mb; };
 __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, const uint8_t *enc, int ip_, int xoff_, int yoff_,
                                                   int n_, int flags_, int mvp0_, int mvp1_)
 {
@@ -258,16 +261,21 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
         for (int k = 0; k < 4; k++) e[k] = lds4(encl + (py + k) * 16 + px);
         if (satd) pk_cols(e, ec);
         const gp8 lb = (gp8)F.luma_base;
-        const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size;
+        const uint32_t stride = PCAMV_LROW, psz = (uint32_t)F.plane_size, lskip = (uint32_t)F.lskip;
         const gp8 lb1 = lb + stride, lb2 = lb1 + stride, lb3 = lb2 + stride;
-        const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
+        const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride, colbase = (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
         const int cpp = 64 >> lgn;
         for (int p0 = 0; p0 < n; p0 += cpp) {
             const int c = p0 + slot;
             const uint32_t xy = L->cxy[c < n ? c : 0];
             const bool act = c < n && xy != CAND_NONE;
             const int mvx = act ? (int)(int16_t)(xy & 0xffffu) : 0, mvy = act ? (int)(int16_t)(xy >> 16) : 0;
-            const uint32_t o = rowbase + (uint32_t)((mvy >> 2) * (int)stride + (mvx >> 2));
+            const uint32_t o = rowbase + (uint32_t)((mvy >> 2) * (int)stride) + lsw_x(colbase + (uint32_t)(mvx >> 2), lskip);
+            /* the candidate's MV bits (L1-resident table) are asked for BEFORE its pixels, and both are waited for together: left
+             * where it is used, the look-up ends up inside the blk == 0 branch behind the pixels' s_waitcnt -- a second memory
+             * round trip in every pass */
+            int mvb0 = 0, mvb1 = 0;
+            if (!(flags & EV_NOMV)) { mvb0 = (int)cost_tab[(uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)]; mvb1 = (int)cost_tab[(uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)]; }
             uint32_t r[4];
             if (flags & EV_WIN) {
                 const int dx = mvx & 3, dy = mvy & 3;
@@ -293,6 +301,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
                     r[2] = avg4(r[2], gld4(lb2, ob)); r[3] = avg4(r[3], gld4(lb3, ob));
                 }
             }
+            asm volatile("" : "+v"(mvb0), "+v"(mvb1), "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
             int v;
             if (satd) v = satd4x4_half(ec, r);
             else {
@@ -301,8 +310,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
                 for (int k = 0; k < 4; k++) sa = __builtin_amdgcn_sad_u8(e[k], r[k], sa);
                 v = (int)sa;
             }
-            v = group_sum(v, nblk);
-            if (!(flags & EV_NOMV)) v += (int)cost_tab[(uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)] + (int)cost_tab[(uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)];
+            v = group_sum(v, nblk) + mvb0 + mvb1;
             if (blk == 0 && c < n) L->ccost[c] = act ? v : PCAMV_COST_MAX;
             if (blk == 0 && act) key_acc = imin(key_acc, (v << 6) | c);
         }
@@ -383,7 +391,7 @@ static __device__ __noinline__ EvalRes eval_list_fn(EvalEnv E, MBLocal *L, const
     EvalEnv U;
     U.cost_mv = (const int16_t *)rfl64((uint64_t)E.cost_mv); U.luma_base = (const uint8_t *)rfl64((uint64_t)E.luma_base); U.chroma_base = (const uint8_t *)rfl64((uint64_t)E.chroma_base);
     U.plane_size = (long long)rfl64((uint64_t)E.plane_size); U.cplane_size = (long long)rfl64((uint64_t)E.cplane_size);
-    U.stride = rfl(E.stride); U.cstride = rfl(E.cstride); U.trace = (int *)rfl64((uint64_t)E.trace); U.trace_mb = rfl(E.trace_mb);
+    U.lskip = rfl(E.lskip); U.cstride = rfl(E.cstride); U.trace = (int *)rfl64((uint64_t)E.trace); U.trace_mb = rfl(E.trace_mb);
     return eval_list_body(U, L, enc, ip, xoff, yoff, n, flags, mvp0, mvp1);
 }
 #endif
@@ -391,7 +399,7 @@ __device__ __forceinline__ EvalRes prim_eval_list(const FrameDev &F, MBLocal *L,
 {
     EvalEnv E;
     E.cost_mv = F.cost_mv; E.luma_base = F.luma_base; E.chroma_base = F.chroma_base[0]; E.plane_size = F.plane_size; E.cplane_size = F.cplane_size;
-    E.stride = F.stride; E.cstride = F.cstride; E.trace = F.trace; E.trace_mb = F.trace_mb;
+    E.lskip = F.lskip; E.cstride = F.cstride; E.trace = F.trace; E.trace_mb = F.trace_mb;
 #ifdef PCAMV_EVAL_CALL
     return eval_list_fn(E, L, enc, ip, xoff, yoff, n, flags, mvp0, mvp1);
 #else
@@ -420,19 +428,21 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
 #pragma unroll
     for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + (py + k) * 16 + px);
     const gp8 lb = (gp8)F.luma_base;
-    const uint32_t stride = (uint32_t)F.stride;
+    const uint32_t stride = PCAMV_LROW, lskip = (uint32_t)F.lskip;
     const gp8 lb1 = lb + stride, lb2 = lb1 + stride, lb3 = lb2 + stride;
-    const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
+    const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride, colbase = (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
     int best = 0x7fffffff;
     for (int r0 = 0; r0 < nrows; r0 += nslot) {
         const int ry = r0 + slot;
         const bool rowok = ry < nrows;
         const int my = min_y + (rowok ? ry : 0);
         const int ycost = (int)cost_tab[(uint32_t)(my * 4 - mvp1 + PCAMV_COST_MV_CENTRE)];
-        const uint32_t orow = rowbase + (uint32_t)(my * (int)stride + min_x);
+        const uint32_t orow = rowbase + (uint32_t)(my * (int)stride);
         for (int x0 = 0; x0 < width; x0 += 4) {
-            const uint32_t o = orow + (uint32_t)x0;
-            const uint64_t w0 = gld8(lb, o), w1 = gld8(lb1, o), w2 = gld8(lb2, o), w3 = gld8(lb3, o);
+            /* 8 bytes of a row as two 4-byte fetches: the second may lie in the next strip */
+            const uint32_t xa = colbase + (uint32_t)(min_x + x0), o = orow + lsw_x(xa, lskip), o4 = orow + lsw_x(xa + 4u, lskip);
+            const uint64_t w0 = gld4(lb, o) | (uint64_t)gld4(lb, o4) << 32, w1 = gld4(lb1, o) | (uint64_t)gld4(lb1, o4) << 32;
+            const uint64_t w2 = gld4(lb2, o) | (uint64_t)gld4(lb2, o4) << 32, w3 = gld4(lb3, o) | (uint64_t)gld4(lb3, o4) << 32;
             uint32_t s[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -478,14 +488,14 @@ __device__ __forceinline__ void prim_tesa_row(const FrameDev &F, MBLocal *L, int
     const int bw = pix_w_of(ip), bh = pix_h_of(ip), sub = ip <= PIX_8x8 ? 8 : 4;
     const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     const gp8 lb = (gp8)F.luma_base;
-    const uint32_t stride = (uint32_t)F.stride;
+    const uint32_t stride = PCAMV_LROW, lskip = (uint32_t)F.lskip;
     PCAMV_WAVE_SYNC();
     if (lane < width) {
-        const uint32_t base = (uint32_t)(L->mb_y * 16 + yoff + my + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + xoff + min_x + lane + PCAMV_PAD);
+        const uint32_t base = (uint32_t)(L->mb_y * 16 + yoff + my + PCAMV_PAD) * stride, colbase = (uint32_t)(L->mb_x * 16 + xoff + min_x + lane + PCAMV_PAD);
         int sad = 0, rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, es0 = 0, es1 = 0, es2 = 0, es3 = 0;
         for (int r = 0; r < bh; r++)
             for (int j = 0; j < bw; j += 4) {
-                const uint32_t ref = gld4(lb, base + (uint32_t)r * stride + (uint32_t)j), e = lds4(L->fenc + (yoff + r) * 16 + xoff + j);
+                const uint32_t ref = gld4(lb, base + (uint32_t)r * stride + lsw_x(colbase + (uint32_t)j, lskip)), e = lds4(L->fenc + (yoff + r) * 16 + xoff + j);
                 sad = (int)__builtin_amdgcn_sad_u8(ref, e, (uint32_t)sad);
                 const int rsum = (int)__builtin_amdgcn_sad_u8(ref, 0u, 0u), esum = (int)__builtin_amdgcn_sad_u8(e, 0u, 0u);
                 const int k = (r >= sub ? 2 : 0) + (j >= sub ? 1 : 0);
@@ -613,8 +623,8 @@ __device__ __forceinline__ void prim_load_fenc(const FrameDev &F, MBLocal *L)
 __device__ __forceinline__ uint32_t luma_row4(const FrameDev &F, int gx, int gy, int mvx, int mvy)
 {
     const gp8 lb = (gp8)F.luma_base;
-    const uint32_t stride = (uint32_t)F.stride, psz = (uint32_t)F.plane_size;
-    const uint32_t o = (uint32_t)(gy + PCAMV_PAD + (mvy >> 2)) * stride + (uint32_t)(gx + PCAMV_PAD + (mvx >> 2));
+    const uint32_t stride = PCAMV_LROW, psz = (uint32_t)F.plane_size;
+    const uint32_t o = (uint32_t)(gy + PCAMV_PAD + (mvy >> 2)) * stride + lsw_x((uint32_t)(gx + PCAMV_PAD + (mvx >> 2)), (uint32_t)F.lskip);
     const int dx = mvx & 3, dy = mvy & 3;
     uint32_t r = gld4(lb, o + (uint32_t)((dx != 0) + 2 * (dy == 2)) * psz + (dy == 3 ? stride : 0u));
     if ((dx | dy) & 1) r = avg4(r, gld4(lb, o + (dy ? (uint32_t)(2 + (dx == 2)) * psz : 0u) + (dx == 3)));
