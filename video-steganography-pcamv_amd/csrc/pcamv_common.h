@@ -236,7 +236,7 @@ struct EvalRes { int cost, idx; };
 #define FOR_CAND(c, n) for (int c = 0; c < (n); c++)
 #define NB_SLOT(i) (i)          /* where iteration i of a FOR_CAND loop keeps a value for a later FOR_CAND loop: element i on the CPU */
 #else
-#define FOR_CAND(c, n) for (int c = (int)(threadIdx.x & 63), c##_1 = 1; c##_1 && c < (n); c##_1 = 0)
+#define FOR_CAND(c, n) for (int c = LANE(), c##_1 = 1; c##_1 && c < (n); c##_1 = 0)
 #define NB_SLOT(i) 0           /* ... the lane's own register on the GPU (the body runs once per lane) */
 #endif
 

@@ -18,7 +18,12 @@
 #define PCAMV_PRIMS_GPU_H
 #include "pcamv_common.h"
 
-#define LANE() ((int)(threadIdx.x & 63))
+/* The lane number passes through an empty asm wherever it is asked for: the compiler then cannot move what is computed from it
+ * (lane == k flags, lane-derived offsets: dozens of values) out of the persistent kernel's macroblock loop, where they lived for
+ * the whole launch -- in scratch, reloaded at ~800 sites of the RD instance, every reload a memory round trip of its own in front
+ * of the instruction that needs it.  Recomputing them where they are used is one or two VALU instructions. */
+__device__ __forceinline__ int pcamv_lane_id(void) { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); return l; }
+#define LANE() pcamv_lane_id()
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t lds4(const uint8_t *p) { return *(const uint32_t *)p; }
 __device__ __forceinline__ void sts4(uint8_t *p, uint32_t v) { *(uint32_t *)p = v; }
