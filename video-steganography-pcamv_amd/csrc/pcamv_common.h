@@ -38,7 +38,7 @@
 #define PCAMV_LSW 28
 #define PCAMV_LROW 32
 #define PCAMV_LSTRIPS(stride) (((stride) + PCAMV_LSW - 1) / PCAMV_LSW + 1)
-#define PCAMV_LSTRIP_OF(x) (((uint32_t)(x) * 18725u) >> 19)          /* x / 28 for x < 40000 */
+#define PCAMV_LSTRIP_OF(x) (((uint32_t)(x) * 18725u) >> 19)          /* x / 28 for x < 40000 (device code: v_mul_u32_u24, see lsw_x) */
 #define PCAMV_COST_MAX (1 << 28)
 #define PCAMV_COST_MV_LEN (4 * 4 * 2048 + 1)
 #define PCAMV_COST_MV_CENTRE (2 * 4 * 2048)

@@ -103,7 +103,11 @@ __device__ __forceinline__ uint32_t gld4(gp8 base, uint32_t off) { return *(cons
 __device__ __forceinline__ uint64_t gld8(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u64u *)(base + off); }
 /* luma planes are strips (pcamv_common.h): the x part of a pixel's byte offset; the y part is y * PCAMV_LROW.  4 bytes from there
  * (and from x + 1: the repeated columns) lie in one strip */
-__device__ __forceinline__ uint32_t lsw_x(uint32_t x, uint32_t lskip) { return __umul24(PCAMV_LSTRIP_OF(x), lskip) + x; }
+/* 32-bit integer multiplies run at a quarter of the VALU rate on this chip; where both factors are known to stay below 2^24
+ * (pixel coordinates, strides, quantiser factors, bilinear weights, levels) the 24-bit forms give the same low 32 bits at full rate */
+__device__ __forceinline__ uint32_t mul24u(uint32_t a, uint32_t b) { return __umul24(a, b); }
+__device__ __forceinline__ int mul24s(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ uint32_t lsw_x(uint32_t x, uint32_t lskip) { return mul24u(mul24u(x, 18725u) >> 19, lskip) + x; }
 __device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
 __device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
 
@@ -156,7 +160,7 @@ __device__ __forceinline__ void chroma_rows_load(gp8 cb, uint32_t cstride, uint3
 __device__ __forceinline__ void chroma_block4_rows(const uint64_t row[5], int mvx, int mvy, uint32_t r[4])
 {
     const int dx = mvx & 7, dy = mvy & 7;
-    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    const uint32_t W = mul24u(8 - dx, 8 - dy) | mul24u(dx, 8 - dy) << 8 | mul24u(8 - dx, dy) << 16 | mul24u(dx, dy) << 24;
     uint32_t w[5][4];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -213,7 +217,7 @@ __device__ __forceinline__ void prim_win_load(const FrameDev &F, MBLocal *L, int
 __device__ __forceinline__ void chroma_block4_win(const MBLocal *L, int b, int mvx, int mvy, uint32_t r[4])
 {
     const int dx = mvx & 7, dy = mvy & 7;
-    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    const uint32_t W = mul24u(8 - dx, 8 - dy) | mul24u(dx, 8 - dy) << 8 | mul24u(8 - dx, dy) << 16 | mul24u(dx, dy) << 24;
     const uint32_t sh = (uint32_t)(b & 3) * 8u;
     uint32_t w[5][4];
 #pragma unroll
@@ -298,10 +302,10 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
             } else {
                 /* get_ref (mc.c:194-243): plane pair by the quarter-pel phase, in arithmetic form of hpel_ref0/1 */
                 const int dx = mvx & 3, dy = mvy & 3;
-                const uint32_t oa = o + (uint32_t)((dx != 0) + 2 * (dy == 2)) * psz + (dy == 3 ? stride : 0u);
+                const uint32_t oa = o + (dx != 0 ? psz : 0u) + (dy == 2 ? 2u * psz : 0u) + (dy == 3 ? stride : 0u);
                 r[0] = gld4(lb, oa); r[1] = gld4(lb1, oa); r[2] = gld4(lb2, oa); r[3] = gld4(lb3, oa);
                 if ((dx | dy) & 1) {
-                    const uint32_t ob = o + (dy ? (uint32_t)(2 + (dx == 2)) * psz : 0u) + (dx == 3);
+                    const uint32_t ob = o + (dy ? (dx == 2 ? 3u * psz : 2u * psz) : 0u) + (dx == 3);
                     r[0] = avg4(r[0], gld4(lb, ob)); r[1] = avg4(r[1], gld4(lb1, ob));
                     r[2] = avg4(r[2], gld4(lb2, ob)); r[3] = avg4(r[3], gld4(lb3, ob));
                 }
@@ -332,7 +336,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
         if (satd) pk_cols(e, ec);
         const gp8 cb = (gp8)F.chroma_base;
         const uint32_t cstride = (uint32_t)F.cstride;
-        const uint32_t rowbase = (uint32_t)plane * (uint32_t)F.cplane_size + (uint32_t)(L->mb_y * 8 + py + PCAMV_CPAD) * cstride + (uint32_t)(L->mb_x * 8 + px + PCAMV_CPAD);
+        const uint32_t rowbase = (plane ? (uint32_t)F.cplane_size : 0u) + mul24u((uint32_t)(L->mb_y * 8 + py + PCAMV_CPAD), cstride) + (uint32_t)(L->mb_x * 8 + px + PCAMV_CPAD);
         const int cpp = 64 >> (lgnb + 1);
         for (int p0 = 0; p0 < n; p0 += cpp) {
             const int c = p0 + slot;
@@ -344,7 +348,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
                 chroma_block4_win(L, 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + py + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW
                                          + (L->mb_x * 8 + px + PCAMV_CPAD + (mvx >> 3) - L->win_cx0), mvx, mvy, r);
             else
-                chroma_block4(cb, cstride, rowbase + (uint32_t)((mvy >> 3) * (int)cstride + (mvx >> 3)), mvx, mvy, r);
+                chroma_block4(cb, cstride, rowbase + (uint32_t)(mul24s(mvy >> 3, (int)cstride) + (mvx >> 3)), mvx, mvy, r);
             int v;
             if (satd) v = satd4x4_half(ec, r);
             else {
@@ -631,8 +635,8 @@ __device__ __forceinline__ uint32_t luma_row4(const FrameDev &F, int gx, int gy,
     const uint32_t stride = PCAMV_LROW, psz = (uint32_t)F.plane_size;
     const uint32_t o = (uint32_t)(gy + PCAMV_PAD + (mvy >> 2)) * stride + lsw_x((uint32_t)(gx + PCAMV_PAD + (mvx >> 2)), (uint32_t)F.lskip);
     const int dx = mvx & 3, dy = mvy & 3;
-    uint32_t r = gld4(lb, o + (uint32_t)((dx != 0) + 2 * (dy == 2)) * psz + (dy == 3 ? stride : 0u));
-    if ((dx | dy) & 1) r = avg4(r, gld4(lb, o + (dy ? (uint32_t)(2 + (dx == 2)) * psz : 0u) + (dx == 3)));
+    uint32_t r = gld4(lb, o + (dx != 0 ? psz : 0u) + (dy == 2 ? 2u * psz : 0u) + (dy == 3 ? stride : 0u));
+    if ((dx | dy) & 1) r = avg4(r, gld4(lb, o + (dy ? (dx == 2 ? 3u * psz : 2u * psz) : 0u) + (dx == 3)));
     return r;
 }
 /* two horizontally adjacent chroma pixels of mc_chroma at chroma position (cx,cy), in bits 0..15 */
@@ -640,9 +644,9 @@ __device__ __forceinline__ uint32_t chroma_px2(const FrameDev &F, int plane, int
 {
     const gp8 cb = (gp8)F.chroma_base[0];
     const uint32_t cstride = (uint32_t)F.cstride;
-    const uint32_t o = (uint32_t)plane * (uint32_t)F.cplane_size + (uint32_t)(cy + PCAMV_CPAD + (mvy >> 3)) * cstride + (uint32_t)(cx + PCAMV_CPAD + (mvx >> 3));
+    const uint32_t o = (plane ? (uint32_t)F.cplane_size : 0u) + mul24u((uint32_t)(cy + PCAMV_CPAD + (mvy >> 3)), cstride) + (uint32_t)(cx + PCAMV_CPAD + (mvx >> 3));
     const int dx = mvx & 7, dy = mvy & 7;
-    const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+    const uint32_t W = mul24u(8 - dx, 8 - dy) | mul24u(dx, 8 - dy) << 8 | mul24u(8 - dx, dy) << 16 | mul24u(dx, dy) << 24;
     const uint32_t a = gld4(cb, o), b = gld4(cb + cstride, o);
     const uint32_t p0 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b, a, 0x05040100u), W, 32u, false) >> 6;
     const uint32_t p1 = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(b, a, 0x06050201u), W, 32u, false) >> 6;
@@ -670,7 +674,7 @@ __device__ __forceinline__ void prim_predict_mb(const FrameDev &F, MBLocal *L, i
         if (win) {
             const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + row + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
             const int dx = mvx & 7, dy = mvy & 7;
-            const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+            const uint32_t W = mul24u(8 - dx, 8 - dy) | mul24u(dx, 8 - dy) << 8 | mul24u(8 - dx, dy) << 16 | mul24u(dx, dy) << 24;
             const uint32_t a = wld4(L, b), bb = wld4(L, b + WIN_CW);
             t = (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x05040100u), W, 32u, false) >> 6)
               | (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x06050201u), W, 32u, false) >> 6) << 8;
@@ -713,7 +717,7 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
         constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of the zigzag) */
         const int cls = (i & 1) + ((i >> 2) & 1), mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bias = cls == 0 ? bs0 : cls == 1 ? bs1 : bs2;
         int c = d[i];
-        c = c > 0 ? ((bias + c) * mf >> 16) : -((bias - c) * mf >> 16);
+        c = c > 0 ? (int)(mul24u((uint32_t)(bias + c), (uint32_t)mf) >> 16) : -(int)(mul24u((uint32_t)(bias - c), (uint32_t)mf) >> 16);   /* bias + |c| < 2^17, mf < 2^16 */
         d[i] = (int16_t)c;
         zm |= (unsigned)(c != 0) << zzinv[i];
         big |= (unsigned)(c + 1) > 2u;
@@ -743,7 +747,7 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int cls = (i & 1) + ((i >> 2) & 1), dqv = cls == 0 ? dq0 : cls == 1 ? dq1 : dq2;
-            d[i] = qbits >= 0 ? (int16_t)((d[i] * dqv) << qbits) : (int16_t)((d[i] * dqv + (1 << (-qbits - 1))) >> (-qbits));
+            d[i] = qbits >= 0 ? (int16_t)(mul24s(d[i], dqv) << qbits) : (int16_t)((mul24s(d[i], dqv) + (1 << (-qbits - 1))) >> (-qbits));
         }
     }
     *nz_out = nz; *score_out = score;
@@ -950,7 +954,7 @@ __device__ __forceinline__ void prim_predict_win16(const FrameDev &F, MBLocal *L
       sts4(dst + row * 16 + 4 * c4, v); }
     { const int plane = lane >> 5, row = (lane & 31) >> 2, c2 = lane & 3, dx = mvx & 7, dy = mvy & 7;
       const int b = 4 * WIN_LP + plane * WIN_CP + (L->mb_y * 8 + row + PCAMV_CPAD + (mvy >> 3) - L->win_cy0) * WIN_CW + (L->mb_x * 8 + 2 * c2 + PCAMV_CPAD + (mvx >> 3) - L->win_cx0);
-      const uint32_t W = (uint32_t)((8 - dx) * (8 - dy)) | (uint32_t)(dx * (8 - dy)) << 8 | (uint32_t)((8 - dx) * dy) << 16 | (uint32_t)(dx * dy) << 24;
+      const uint32_t W = mul24u(8 - dx, 8 - dy) | mul24u(dx, 8 - dy) << 8 | mul24u(8 - dx, dy) << 16 | mul24u(dx, dy) << 24;
       const uint32_t a = wld4(L, b), bb = wld4(L, b + WIN_CW);
       const uint32_t t = (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x05040100u), W, 32u, false) >> 6)
                        | (__builtin_amdgcn_udot4(__builtin_amdgcn_perm(bb, a, 0x06050201u), W, 32u, false) >> 6) << 8;

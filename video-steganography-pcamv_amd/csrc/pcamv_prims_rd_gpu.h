@@ -150,7 +150,7 @@ __device__ __forceinline__ void prim_intra16_satd(const FrameDev &F, MBLocal *L,
         for (int y = 0; y < 4; y++) {
             uint32_t o = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + b * (px + x - 7) + c * (py + y - 7) + 16) >> 5, 0, 255) << (8 * x);
+            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + mul24s(b, px + x - 7) + mul24s(c, py + y - 7) + 16) >> 5, 0, 255) << (8 * x);
             r[y] = o;
         }
     }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void prim_intra8c_satd(const FrameDev &F, MBLocal *L,
             for (int y = 0; y < 4; y++) {
                 uint32_t o = 0;
 #pragma unroll
-                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + b * (px + x - 3) + c * (py + y - 3) + 16) >> 5, 0, 255) << (8 * x);
+                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + mul24s(b, px + x - 3) + mul24s(c, py + y - 3) + 16) >> 5, 0, 255) << (8 * x);
                 r[y] = o;
             }
         }
@@ -339,9 +339,9 @@ __device__ __forceinline__ void prim_intra4_encode(const FrameDev &F, MBLocal *L
         const int mf = cls == 0 ? F.q_mf_i[0] : cls == 1 ? F.q_mf_i[1] : F.q_mf_i[2], bias = cls == 0 ? F.q_bias_i[0] : cls == 1 ? F.q_bias_i[1] : F.q_bias_i[2];
         const int dq = cls == 0 ? F.dq_mf[0] : cls == 1 ? F.dq_mf[1] : F.dq_mf[2];
         int v = d[i];
-        v = v > 0 ? ((bias + v) * mf >> 16) : -((bias - v) * mf >> 16);
+        v = v > 0 ? (int)(mul24u((uint32_t)(bias + v), (uint32_t)mf) >> 16) : -(int)(mul24u((uint32_t)(bias - v), (uint32_t)mf) >> 16);
         nz |= v;
-        c[i] = qbits >= 0 ? (int16_t)((v * dq) << qbits) : (int16_t)((v * dq + (1 << (-qbits - 1))) >> (-qbits));
+        c[i] = qbits >= 0 ? (int16_t)(mul24s(v, dq) << qbits) : (int16_t)((mul24s(v, dq) + (1 << (-qbits - 1))) >> (-qbits));
     }
     if (nz) {
         /* add4x4_idct (dct.c:174-216) on top of the prediction rows */
@@ -438,7 +438,7 @@ __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
         for (int k = 0; k < 4; k++) {
             const uint32_t e = lds4(L->fenc + (py + k) * 16 + px), p = lds4(L->pred + (py + k) * 16 + px);
 #pragma unroll
-            for (int x = 0; x < 4; x++) { const int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += dd * dd; }
+            for (int x = 0; x < 4; x++) { const int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += mul24s(dd, dd); }
         }
     }
     int ssd = wave_sum_all(v);

@@ -27,7 +27,9 @@
 #define PCAMV_RD_OCC 1
 #define RD_NAME(x) x##_lo
 #else
+#ifndef PCAMV_RD_OCC
 #define PCAMV_RD_OCC 4
+#endif
 #define RD_NAME(x) x
 #endif
 #include "pcamv_kernels.hip.h"
