@@ -83,27 +83,36 @@ PCAMV_DEV void predict_mv_pskip(MBLocal *L, int mv[2])
 PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
 {
     int i = 0, xy = L->mb_xy, top = xy - F.mb_w;
-#define SETMV(mb) { const uint32_t w_ = NB_LD32(&F.mvr[2 * (mb)]); mvc[i][0] = (int16_t)(w_ & 0xffff); mvc[i][1] = (int16_t)(w_ >> 16); i++; }
-    if ((L->neighbour & NB_LEFT) && L->type_left != PCAMV_P_SKIP) SETMV(xy - 1);
-    if (L->neighbour & NB_TOP) {
-        if (L->type_top != PCAMV_P_SKIP) SETMV(top);
-        if ((L->neighbour & NB_TOPLEFT) && L->type_topleft != PCAMV_P_SKIP) SETMV(top - 1);
-        if (L->mb_x < F.mb_w - 1 && L->type_topright != PCAMV_P_SKIP) SETMV(top + 1);
-    }
+    /* every candidate is requested before the first is used (a neighbour that does not count reads this macroblock's own slot):
+     * one memory round trip for the four spatial ones and one for the temporal ones, instead of one per candidate */
+    const int use_l = (L->neighbour & NB_LEFT) && L->type_left != PCAMV_P_SKIP;
+    const int use_t = (L->neighbour & NB_TOP) && L->type_top != PCAMV_P_SKIP;
+    const int use_tl = (L->neighbour & NB_TOP) && (L->neighbour & NB_TOPLEFT) && L->type_topleft != PCAMV_P_SKIP;
+    const int use_tr = (L->neighbour & NB_TOP) && L->mb_x < F.mb_w - 1 && L->type_topright != PCAMV_P_SKIP;
+    const uint32_t w_l = NB_LD32(&F.mvr[2 * (use_l ? xy - 1 : xy)]), w_t = NB_LD32(&F.mvr[2 * (use_t ? top : xy)]);
+    const uint32_t w_tl = NB_LD32(&F.mvr[2 * (use_tl ? top - 1 : xy)]), w_tr = NB_LD32(&F.mvr[2 * (use_tr ? top + 1 : xy)]);
+#define SETMV(w_) { mvc[i][0] = (int16_t)((w_) & 0xffff); mvc[i][1] = (int16_t)((w_) >> 16); i++; }
+    if (use_l) SETMV(w_l);
+    if (use_t) SETMV(w_t);
+    if (use_tl) SETMV(w_tl);
+    if (use_tr) SETMV(w_tr);
 #undef SETMV
     if (F.have_prev) {
+        int ok[3], rf[3]; uint32_t mw[3];
         for (int k = 0; k < 3; k++) {
-            int dx = k == 1, dy = k == 2;
-            if (k == 1 && !(L->mb_x < F.mb_w - 1)) continue;
-            if (k == 2 && !(L->mb_y < F.mb_h - 1)) continue;
-            int b4 = 4 * (L->mb_y * 4 * F.mb_w + L->mb_x) + dx * 4 + dy * 4 * (4 * F.mb_w);
-            int b8 = 2 * (L->mb_y * 2 * F.mb_w + L->mb_x) + dx * 2 + dy * 2 * (2 * F.mb_w);
-            if (F.prev_ref[b8] >= 0) {
-                mvc[i][0] = (int16_t)((F.prev_mv[2 * b4] * F.tscale + 128) >> 8);
-                mvc[i][1] = (int16_t)((F.prev_mv[2 * b4 + 1] * F.tscale + 128) >> 8);
+            const int dx = k == 1, dy = k == 2;
+            ok[k] = !(k == 1 && !(L->mb_x < F.mb_w - 1)) && !(k == 2 && !(L->mb_y < F.mb_h - 1));
+            const int b4 = 4 * (L->mb_y * 4 * F.mb_w + L->mb_x) + (ok[k] ? dx * 4 + dy * 4 * (4 * F.mb_w) : 0);
+            const int b8 = 2 * (L->mb_y * 2 * F.mb_w + L->mb_x) + (ok[k] ? dx * 2 + dy * 2 * (2 * F.mb_w) : 0);
+            rf[k] = F.prev_ref[b8];
+            mw[k] = *(const uint32_t *)&F.prev_mv[2 * b4];
+        }
+        for (int k = 0; k < 3; k++)
+            if (ok[k] && rf[k] >= 0) {
+                mvc[i][0] = (int16_t)(((int)(int16_t)(mw[k] & 0xffff) * F.tscale + 128) >> 8);
+                mvc[i][1] = (int16_t)(((int)(int16_t)(mw[k] >> 16) * F.tscale + 128) >> 8);
                 i++;
             }
-        }
     }
     return i;
 }

@@ -23,7 +23,11 @@
  * the whole launch -- in scratch, reloaded at ~800 sites of the RD instance, every reload a memory round trip of its own in front
  * of the instruction that needs it.  Recomputing them where they are used is one or two VALU instructions. */
 __device__ __forceinline__ int pcamv_lane_id(void) { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); return l; }
+#ifdef PCAMV_RD_LO      /* the one-wave-per-SIMD build has the registers to keep them (183 in use): hoisted is 1-2 % faster there */
+#define LANE() ((int)(threadIdx.x & 63))
+#else
 #define LANE() pcamv_lane_id()
+#endif
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t lds4(const uint8_t *p) { return *(const uint32_t *)p; }
 __device__ __forceinline__ void sts4(uint8_t *p, uint32_t v) { *(uint32_t *)p = v; }
