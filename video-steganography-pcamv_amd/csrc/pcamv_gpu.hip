@@ -189,7 +189,9 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         if (e == hipSuccess && F.b_mbrd) {
             /* which build of the RD instance (pcamv_rd.hip): one wave per SIMD while the chains fit that anyway */
             const char *inst = getenv("PCAMV_RD_INSTANCE");
-            b->rd_lo = inst ? !strcmp(inst, "lo") : (b->fl.raster && n <= 4 * n_cu);
+            /* measured (1080p umh subme 7, MB/s lo / hi): 256 chains 2.31 / 2.21 M, 512: 4.43 / 4.19 M, 1024: 6.84 / 7.77 M -- with one
+             * wave per SIMD the lo build has no free wave left at 1024 chains to take the RCA steps off the chains */
+            b->rd_lo = inst ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu);
             per_cu = b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
             if (per_cu < 0) e = hipErrorUnknown;
         }

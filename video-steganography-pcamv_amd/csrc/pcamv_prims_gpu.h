@@ -105,6 +105,9 @@ typedef uint64_t __attribute__((aligned(1))) u64u;
 typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t gld4(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u32u *)(base + off); }
 __device__ __forceinline__ uint64_t gld8(gp8 base, uint32_t off) { return *(const __attribute__((address_space(1))) u64u *)(base + off); }
+/* entry i of the MV-bit table (int16): scalar table base + a 32-bit byte offset (a pointer + index form makes the compiler do
+ * 64-bit vector address arithmetic in every list pass) */
+__device__ __forceinline__ int gld_cost(gp8 tab, uint32_t i) { return (int)*(const __attribute__((address_space(1))) int16_t *)(tab + (i << 1)); }
 /* luma planes are strips (pcamv_common.h): the x part of a pixel's byte offset; the y part is y * PCAMV_LROW.  4 bytes from there
  * (and from x + 1: the repeated columns) lie in one strip */
 /* 32-bit integer multiplies run at a quarter of the VALU rate on this chip; where both factors are known to stay below 2^24
@@ -260,7 +263,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
     const int lane = LANE();
     const int lgn = lg_nblk_of(ip), lgw = lg_w4_of(ip), nblk = 1 << lgn;
     const int satd = flags & EV_SATD;
-    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    const gp8 cost_tab = (gp8)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     PCAMV_WAVE_SYNC();
     const unsigned long long t_ev = PROF_T();
     PROF_CNT(32, 1); PROF_CNT(33, n);
@@ -288,7 +291,7 @@ __device__ __forceinline__ EvalRes eval_list_body(const EvalEnv &F, MBLocal *L, 
              * where it is used, the look-up ends up inside the blk == 0 branch behind the pixels' s_waitcnt -- a second memory
              * round trip in every pass */
             int mvb0 = 0, mvb1 = 0;
-            if (!(flags & EV_NOMV)) { mvb0 = (int)cost_tab[(uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)]; mvb1 = (int)cost_tab[(uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)]; }
+            if (!(flags & EV_NOMV)) { mvb0 = gld_cost(cost_tab, (uint32_t)(mvx - mvp0 + PCAMV_COST_MV_CENTRE)); mvb1 = gld_cost(cost_tab, (uint32_t)(mvy - mvp1 + PCAMV_COST_MV_CENTRE)); }
             uint32_t r[4];
             if (flags & EV_WIN) {
                 const int dx = mvx & 3, dy = mvy & 3;
@@ -435,7 +438,7 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
     const int lgn = lg_nblk_of(ip), lgw = lg_w4_of(ip), nblk = 1 << lgn;
     const int slot = lane >> lgn, blk = lane & (nblk - 1), nslot = 64 >> lgn;
     const int px = xoff + 4 * (blk & ((1 << lgw) - 1)), py = yoff + 4 * (blk >> lgw);
-    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    const gp8 cost_tab = (gp8)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     PCAMV_WAVE_SYNC();
     uint32_t e[4];
 #pragma unroll
@@ -449,7 +452,7 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
         const int ry = r0 + slot;
         const bool rowok = ry < nrows;
         const int my = min_y + (rowok ? ry : 0);
-        const int ycost = (int)cost_tab[(uint32_t)(my * 4 - mvp1 + PCAMV_COST_MV_CENTRE)];
+        const int ycost = gld_cost(cost_tab, (uint32_t)(my * 4 - mvp1 + PCAMV_COST_MV_CENTRE));
         const uint32_t orow = rowbase + (uint32_t)(my * (int)stride);
         for (int x0 = 0; x0 < width; x0 += 4) {
             /* 8 bytes of a row as two 4-byte fetches: the second may lie in the next strip */
@@ -476,7 +479,7 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
                 const int j = nblk >= 4 ? (blk & 3) : jj;
                 const int sad = (j & 2 ? p23 : p01) >> (16 * (j & 1)) & 0xffff;
                 const int mx = min_x + x0 + j;
-                const int cost = sad + ycost + (int)cost_tab[(uint32_t)(mx * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
+                const int cost = sad + ycost + gld_cost(cost_tab, (uint32_t)(mx * 4 - mvp0 + PCAMV_COST_MV_CENTRE));
                 const int key = (cost << 11) | (ry * width + x0 + j);
                 if (rowok && x0 + j < width && key < best) best = key;
             }
@@ -499,7 +502,7 @@ __device__ __forceinline__ void prim_tesa_row(const FrameDev &F, MBLocal *L, int
     const int ip = rfl(ip_), xoff = rfl(xoff_), yoff = rfl(yoff_), min_x = rfl(min_x_), my = rfl(my_), width = rfl(width_), mvp0 = rfl(mvp0_);
     const int lane = LANE();
     const int bw = pix_w_of(ip), bh = pix_h_of(ip), sub = ip <= PIX_8x8 ? 8 : 4;
-    const gp16 cost_tab = (gp16)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    const gp8 cost_tab = (gp8)(F.cost_mv - PCAMV_COST_MV_CENTRE);
     const gp8 lb = (gp8)F.luma_base;
     const uint32_t stride = PCAMV_LROW, lskip = (uint32_t)F.lskip;
     PCAMV_WAVE_SYNC();
@@ -519,8 +522,8 @@ __device__ __forceinline__ void prim_tesa_row(const FrameDev &F, MBLocal *L, int
         const int ads = iabs(es0 - rs0) + iabs(es1 - rs1) + iabs(es2 - rs2) + iabs(es3 - rs3);
         /* me.c:551,563: the SAD of a position is charged cost_fpel_mvx[x] with x RELATIVE to the window (the ADS gets the
          * position's real MV bits, cost_fpel_mvx + min_x) -- the reference's arithmetic, kept */
-        L->ccost[lane] = sad + (int)cost_tab[(uint32_t)(lane * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
-        L->ccost[64 + lane] = ads + (int)cost_tab[(uint32_t)((min_x + lane) * 4 - mvp0 + PCAMV_COST_MV_CENTRE)];
+        L->ccost[lane] = sad + gld_cost(cost_tab, (uint32_t)(lane * 4 - mvp0 + PCAMV_COST_MV_CENTRE));
+        L->ccost[64 + lane] = ads + gld_cost(cost_tab, (uint32_t)((min_x + lane) * 4 - mvp0 + PCAMV_COST_MV_CENTRE));
     }
     PCAMV_WAVE_SYNC();
 }

@@ -9,13 +9,12 @@
  *
  * Two builds of it (this file, and pcamv_rd_lo.hip which includes it with PCAMV_RD_LO defined), differing in the register
  * budget only.  With CABAC a frame is ONE chain of macroblocks (the context states), so a batch of G GOPs keeps G waves busy
- * (+ the RCA work they hand off):
- *   - "lo", 1 wave per SIMD, up to 512 VGPRs, nothing spilled: the fastest macroblock.  Used while the chains fit the
- *     1024 SIMDs anyway (G <= 4 x CUs): G=64 928 ms per 1080p step (measured when the choice was made: G=1024 1485 ms = 5.6 M MB/s);
- *   - "hi", 4 waves per SIMD at 128 VGPRs (149 spilled): a wave is parked on s_waitcnt 62 % of its time (SQ_WAIT_ANY /
- *     SQ_WAVE_CYCLES, profiles/r02_*), so four of them per SIMD raise the throughput although each runs 1.8x slower:
- *     G=4096 14.4 M MB/s (when the choice was made: G=2048 8.2 M, G=4096 11.9 M; 2 waves per SIMD 8.4 M at G=2048; 3: 10.5 M at
- *     G=3072).
+ * (+ the RCA work they hand off to whoever is free):
+ *   - "lo", 1 wave per SIMD, every register (342 VGPRs in use, lane-derived constants hoisted out of the macroblock loop):
+ *     the fastest macroblock.  Used while the chains are few (G <= 2 x CUs): G=64 874 ms per 1080p step, 512: 943 ms = 4.43 M MB/s;
+ *   - "hi", 4 waves per SIMD at 128 VGPRs, nothing spilled (the lane number is laundered, pcamv_prims_gpu.h LANE(): with the
+ *     lane == k flags hoisted it spilled 149 registers and every reload was a memory round trip in front of its use):
+ *     G=1024 7.77 M MB/s (lo: 6.84 M -- no free wave left for the RCA steps), G=4096 18.3 M.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
