@@ -724,7 +724,10 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
         constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of the zigzag) */
         const int cls = (i & 1) + ((i >> 2) & 1), mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bias = cls == 0 ? bs0 : cls == 1 ? bs1 : bs2;
         int c = d[i];
-        c = c > 0 ? (int)(mul24u((uint32_t)(bias + c), (uint32_t)mf) >> 16) : -(int)(mul24u((uint32_t)(bias - c), (uint32_t)mf) >> 16);   /* bias + |c| < 2^17, mf < 2^16 */
+        /* quant.c:33-48: c > 0 ? (bias + c) * mf >> 16 : -((bias - c) * mf >> 16), without the branch the compiler made of it (two arms
+         * per coefficient, each re-reading a dozen parked scalars); bias * mf < 2^16, so c = 0 stays 0; bias + |c| < 2^17, mf < 2^16 */
+        const int qa = (int)(mul24u((uint32_t)(bias + iabs(c)), (uint32_t)mf) >> 16);
+        c = c < 0 ? -qa : qa;
         d[i] = (int16_t)c;
         zm |= (unsigned)(c != 0) << zzinv[i];
         big |= (unsigned)(c + 1) > 2u;

@@ -339,7 +339,8 @@ __device__ __forceinline__ void prim_intra4_encode(const FrameDev &F, MBLocal *L
         const int mf = cls == 0 ? F.q_mf_i[0] : cls == 1 ? F.q_mf_i[1] : F.q_mf_i[2], bias = cls == 0 ? F.q_bias_i[0] : cls == 1 ? F.q_bias_i[1] : F.q_bias_i[2];
         const int dq = cls == 0 ? F.dq_mf[0] : cls == 1 ? F.dq_mf[1] : F.dq_mf[2];
         int v = d[i];
-        v = v > 0 ? (int)(mul24u((uint32_t)(bias + v), (uint32_t)mf) >> 16) : -(int)(mul24u((uint32_t)(bias - v), (uint32_t)mf) >> 16);
+        const int qa = (int)(mul24u((uint32_t)(bias + iabs(v)), (uint32_t)mf) >> 16);      /* branch-free form, see quant_score_dequant */
+        v = v < 0 ? -qa : qa;
         nz |= v;
         c[i] = qbits >= 0 ? (int16_t)(mul24s(v, dq) << qbits) : (int16_t)((mul24s(v, dq) + (1 << (-qbits - 1))) >> (-qbits));
     }
