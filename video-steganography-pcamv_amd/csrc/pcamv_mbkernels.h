@@ -186,7 +186,16 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
 PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int store_rec = 1)
 {
     const int xy = mb_y * F.mb_w + mb_x;
-    const pcamv_mb_t *r = &F.rec_mb[xy];
+    /* the macroblock's record (59 words) and the index of its first carrier come in with ONE memory round trip, into storage that is
+     * idle in this pass (the candidate costs); read field by field from memory, type / partition / sub-partitions / used / MVs were a
+     * dozen dependent round trips at the head of a task that is only ~3 k instructions long */
+    pcamv_mb_t *r = (pcamv_mb_t *)L->ccost;
+    PCAMV_WAVE_SYNC();
+    FOR_CAND(i, (int)(sizeof(pcamv_mb_t) / 4) + 1) {
+        if (i < (int)(sizeof(pcamv_mb_t) / 4)) ((uint32_t *)r)[i] = ((const uint32_t *)&F.rec_mb[xy])[i];
+        else L->ccost[191] = F.car_base ? F.car_base[xy] : 0;
+    }
+    PCAMV_WAVE_SYNC();
     mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
     L->i_type = r->i_type; L->i_partition = r->i_partition;
     for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
@@ -197,12 +206,14 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
     } else {
         int *slots = L->slots;
         const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, r->used, slots);
-        const int base = F.car_base ? F.car_base[xy] : 0;
+        const int base = L->ccost[191];
+        PCAMV_WAVE_SYNC();
+        FOR_CAND(j, n) L->cxy[j] = F.flip ? (uint32_t)(F.flip[base + j] == 1) : 0u;     /* its carriers' flip flags: one more round trip */
         PCAMV_WAVE_SYNC();
         FOR_CAND(i, 16) {
             const int s = carrier_of_block(L->i_type, L->i_partition, L->sub_part, i);
             int flipped = 0;
-            for (int j = 0; j < n; j++) if (slots[j] == s) flipped = F.flip ? F.flip[base + j] == 1 : 0;
+            for (int j = 0; j < n; j++) if (slots[j] == s) flipped = (int)L->cxy[j];
             L->cmv[scan8_of(i)][0] = flipped ? r->mv_stego[s][0] : r->mv[i][0];
             L->cmv[scan8_of(i)][1] = flipped ? r->mv_stego[s][1] : r->mv[i][1];
         }
