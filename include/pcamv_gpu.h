@@ -129,7 +129,9 @@ int pcamv_gpu_set_ref(pcamv_ctx_t *ctx, const uint8_t *const plane[3], const int
                       const int16_t *prev_mv, const int8_t *prev_ref);
 
 /* Read back the 4 padded luma planes produced by set_ref: out must hold 4*stride*lines
- * bytes; *stride = ALIGN(width+64,16), *lines = height+64, origin at (32,32). */
+ * bytes; *stride = ALIGN(width+64,16), *lines = height+64, origin at (32,32).  The caller gets x264's
+ * raster planes (filtered[0..3] with their borders); on the device they are kept in a strip layout
+ * (DESIGN.md section 3), which this call undoes. */
 int pcamv_gpu_get_ref_planes(pcamv_ctx_t *ctx, uint8_t *out, int *stride, int *lines);
 
 /* Pass-1 analysis of the whole P frame at luma QP qp.  out_mb[mb_count] receives the record
