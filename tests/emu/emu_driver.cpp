@@ -69,3 +69,19 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
 }
 
 extern "C" void emu_get_stats(long long *out, int reset) { for (int i = 0; i < 32; i++) { out[i] = emu_stats[i]; if (reset) emu_stats[i] = 0; } }
+
+/* The strip layout of the device's luma planes (pcamv_common.h): the host-side statement of its address arithmetic, for
+ * tests/test_logic_emu.py::test_strip_layout_arithmetic.  Returns the first x for which the multiply-shift strip index differs
+ * from x / 28 (or -1), and fills a small raster -> strip -> raster round trip. */
+extern "C" int emu_strip_index_first_bad(int limit)
+{
+    for (int x = 0; x < limit; x++)
+        if ((int)PCAMV_LSTRIP_OF(x) != x / PCAMV_LSW) return x;
+    return -1;
+}
+extern "C" long long emu_strip_offset(int x, int y, int lines)
+{
+    const long long lskip = (long long)PCAMV_LROW * lines - PCAMV_LSW;
+    return (long long)y * PCAMV_LROW + x + (long long)PCAMV_LSTRIP_OF(x) * lskip;
+}
+extern "C" long long emu_strip_plane_size(int stride, int lines) { return (long long)PCAMV_LSTRIPS(stride) * PCAMV_LROW * lines; }

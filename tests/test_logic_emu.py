@@ -58,3 +58,26 @@ def test_rd_mode_decision_logic_matches_reference(name, order):
         for k, nm in enumerate("yuv"):
             assert np.array_equal(rec[k], g[f"f{t}_rec_{nm}"]), f"{name} frame {t}: recon {nm}"
     o.close()
+
+
+def test_strip_layout_arithmetic():
+    """Device layout of the luma reference planes (pcamv_common.h): the multiply-shift strip index is x / 28 for every x a
+    padded plane can have (up to 8K widths and beyond), a 4-byte fetch at any x -- and at x + 1 -- stays inside one strip's row, distinct
+    pixels of a plane (up to the four repeated columns) never share a byte, and every byte lies inside the plane's allocation."""
+    import ctypes as C
+    lib = C.CDLL(emu.build())
+    lib.emu_strip_offset.restype = C.c_longlong
+    lib.emu_strip_plane_size.restype = C.c_longlong
+    assert lib.emu_strip_index_first_bad(40000) == -1
+    for w, h in ((176, 144), (1920, 1088), (3840, 2160), (7680, 4320)):
+        stride, lines = (w + 64 + 15) & ~15, h + 64
+        psz = lib.emu_strip_plane_size(stride, lines)
+        seen = {}
+        for y in (0, 1, lines // 2, lines - 1):
+            for x in range(stride):
+                o = lib.emu_strip_offset(x, y, lines)
+                assert 0 <= o and o + 4 <= psz
+                assert o % 32 == x % 28 and o % 32 + 1 + 4 <= 32           # bytes x .. x + 4 (fetch at x + 1 included) in one 32-byte row
+                assert seen.setdefault(o, (x, y)) == (x, y)
+                if x % 28 < 4 and x >= 28:                                   # the repeat at the end of the strip before
+                    assert lib.emu_strip_offset(x - 28, y, lines) + 28 == o - (32 * lines - 28)
