@@ -56,6 +56,7 @@ struct FrameDev {
     const uint8_t *fenc[3];
     const uint8_t *raw[3];         /* un-padded reference planes the plane-production kernels read */
     uint8_t *luma_base, *chroma_base[2];   /* start of the padded allocations */
+    uint8_t *luma_raster;          /* --me esa / tesa only: the full-pel plane once more in raster rows (their row primitives walk x-consecutive positions: 8-byte row loads shared by four candidates), else NULL */
     uint8_t *luma[4];              /* CPU emulation of the control code only (tests/emu): picture-origin pointers into RASTER padded planes */
     uint8_t *chroma[2];
     uint8_t *rec[3];               /* pass-1 reconstruction out, tightly packed */

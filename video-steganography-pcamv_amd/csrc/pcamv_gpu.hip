@@ -48,7 +48,7 @@ struct pcamv_ctx {
     FrameDev F;
     EmbedDev E;
     /* device allocations */
-    uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_chroma[2], *d_rec[3];
+    uint8_t *d_fenc[3], *d_raw[3], *d_luma, *d_luma_raster, *d_chroma[2], *d_rec[3];
     int8_t *d_mb_type, *d_ref8, *d_prev_ref, *d_ref8_b;
     int16_t *d_mv, *d_mvr, *d_prev_mv, *d_mvp_aux, *d_mv_b;
     int last_field, prev_internal;   /* ping-pong of the motion field for device-resident chains: which of d_mv (0) / d_mv_b (1) the last analysis wrote */
@@ -310,6 +310,7 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     }
     HIPCHK(c, dalloc(&c->d_luma, 4 * lsz + 64));
     HIPCHK(c, hipMemset(c->d_luma, 0, 4 * lsz + 64));      /* the repeated columns of each plane's last strip are never written */
+    if (F.me_method == PCAMV_ME_ESA || F.me_method == PCAMV_ME_TESA) HIPCHK(c, dalloc(&c->d_luma_raster, (size_t)F.stride * F.lines + 64));
     HIPCHK(c, dalloc(&c->d_chroma[0], 2 * (csz + 64))); c->d_chroma[1] = c->d_chroma[0] + csz + 64;   /* one allocation: 32-bit offsets reach both */
     F.cplane_size = (long long)(csz + 64);
     HIPCHK(c, dalloc(&c->d_mb_type, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_ref8, (size_t)F.n_mb * 4)); HIPCHK(c, dalloc(&c->d_prev_ref, (size_t)F.n_mb * 4));
@@ -344,6 +345,7 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     long long lcg = 1; HIPCHK(c, hipMemcpy(c->d_lcg, &lcg, sizeof(lcg), hipMemcpyHostToDevice));
     for (int i = 0; i < 3; i++) { F.fenc[i] = c->d_fenc[i]; F.rec[i] = c->d_rec[i]; F.raw[i] = c->d_raw[i]; }
     F.luma_base = c->d_luma; F.chroma_base[0] = c->d_chroma[0]; F.chroma_base[1] = c->d_chroma[1];
+    F.luma_raster = c->d_luma_raster;
     for (int k = 0; k < 2; k++) F.chroma[k] = c->d_chroma[k] + (size_t)F.cstride * PCAMV_CPAD + PCAMV_CPAD;
     F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
     F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
@@ -368,7 +370,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
         for (int i = 0; i < b->n; i++) if (b->ctx[i] == c) b->ctx[i] = NULL;
     }
     for (int i = 0; i < 3; i++) { hipFree(c->d_fenc[i]); hipFree(c->d_raw[i]); hipFree(c->d_rec[i]); }
-    hipFree(c->d_luma); hipFree(c->d_chroma[0]);
+    hipFree(c->d_luma); hipFree(c->d_luma_raster); hipFree(c->d_chroma[0]);
     hipFree(c->d_mb_type); hipFree(c->d_ref8); hipFree(c->d_prev_ref); hipFree(c->d_mv); hipFree(c->d_prev_mv); hipFree(c->d_mvr);
     hipFree(c->d_mvp_aux); hipFree(c->d_rec_mb); hipFree(c->d_mv_b); hipFree(c->d_ref8_b);
     for (int q = 0; q < 52; q++) if (c->d_cost_mv[q]) hipFree(c->d_cost_mv[q]);

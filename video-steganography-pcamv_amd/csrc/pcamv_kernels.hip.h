@@ -135,6 +135,7 @@ static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__re
          * of the strip before it */
         const size_t o = (size_t)y * PCAMV_LROW + strip_o;
         *(uint32_t *)(planes + o) = of;
+        if (F.luma_raster) *(uint32_t *)(F.luma_raster + (size_t)y * stride + x0) = of;
         *(uint32_t *)(planes + psz + o) = oh;
         *(uint32_t *)(planes + 2 * psz + o) = ov;
         *(uint32_t *)(planes + 3 * psz + o) = oc;

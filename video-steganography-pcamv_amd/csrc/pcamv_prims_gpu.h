@@ -443,22 +443,20 @@ __device__ __forceinline__ EvalRes prim_esa_window(const FrameDev &F, MBLocal *L
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) e[k] = lds4(L->fenc + (py + k) * 16 + px);
-    const gp8 lb = (gp8)F.luma_base;
-    const uint32_t stride = PCAMV_LROW, lskip = (uint32_t)F.lskip;
+    const gp8 lb = (gp8)F.luma_raster;         /* the raster copy of the full-pel plane (FrameDev): x-consecutive positions share their row loads */
+    const uint32_t stride = (uint32_t)F.stride;
     const gp8 lb1 = lb + stride, lb2 = lb1 + stride, lb3 = lb2 + stride;
-    const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride, colbase = (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
+    const uint32_t rowbase = (uint32_t)(L->mb_y * 16 + py + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + px + PCAMV_PAD);
     int best = 0x7fffffff;
     for (int r0 = 0; r0 < nrows; r0 += nslot) {
         const int ry = r0 + slot;
         const bool rowok = ry < nrows;
         const int my = min_y + (rowok ? ry : 0);
         const int ycost = gld_cost(cost_tab, (uint32_t)(my * 4 - mvp1 + PCAMV_COST_MV_CENTRE));
-        const uint32_t orow = rowbase + (uint32_t)(my * (int)stride);
+        const uint32_t orow = rowbase + (uint32_t)(my * (int)stride + min_x);
         for (int x0 = 0; x0 < width; x0 += 4) {
-            /* 8 bytes of a row as two 4-byte fetches: the second may lie in the next strip */
-            const uint32_t xa = colbase + (uint32_t)(min_x + x0), o = orow + lsw_x(xa, lskip), o4 = orow + lsw_x(xa + 4u, lskip);
-            const uint64_t w0 = gld4(lb, o) | (uint64_t)gld4(lb, o4) << 32, w1 = gld4(lb1, o) | (uint64_t)gld4(lb1, o4) << 32;
-            const uint64_t w2 = gld4(lb2, o) | (uint64_t)gld4(lb2, o4) << 32, w3 = gld4(lb3, o) | (uint64_t)gld4(lb3, o4) << 32;
+            const uint32_t o = orow + (uint32_t)x0;
+            const uint64_t w0 = gld8(lb, o), w1 = gld8(lb1, o), w2 = gld8(lb2, o), w3 = gld8(lb3, o);
             uint32_t s[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -503,15 +501,15 @@ __device__ __forceinline__ void prim_tesa_row(const FrameDev &F, MBLocal *L, int
     const int lane = LANE();
     const int bw = pix_w_of(ip), bh = pix_h_of(ip), sub = ip <= PIX_8x8 ? 8 : 4;
     const gp8 cost_tab = (gp8)(F.cost_mv - PCAMV_COST_MV_CENTRE);
-    const gp8 lb = (gp8)F.luma_base;
-    const uint32_t stride = PCAMV_LROW, lskip = (uint32_t)F.lskip;
+    const gp8 lb = (gp8)F.luma_raster;         /* raster copy of the full-pel plane, as in prim_esa_window */
+    const uint32_t stride = (uint32_t)F.stride;
     PCAMV_WAVE_SYNC();
     if (lane < width) {
-        const uint32_t base = (uint32_t)(L->mb_y * 16 + yoff + my + PCAMV_PAD) * stride, colbase = (uint32_t)(L->mb_x * 16 + xoff + min_x + lane + PCAMV_PAD);
+        const uint32_t base = (uint32_t)(L->mb_y * 16 + yoff + my + PCAMV_PAD) * stride + (uint32_t)(L->mb_x * 16 + xoff + min_x + lane + PCAMV_PAD);
         int sad = 0, rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, es0 = 0, es1 = 0, es2 = 0, es3 = 0;
         for (int r = 0; r < bh; r++)
             for (int j = 0; j < bw; j += 4) {
-                const uint32_t ref = gld4(lb, base + (uint32_t)r * stride + lsw_x(colbase + (uint32_t)j, lskip)), e = lds4(L->fenc + (yoff + r) * 16 + xoff + j);
+                const uint32_t ref = gld4(lb, base + (uint32_t)r * stride + (uint32_t)j), e = lds4(L->fenc + (yoff + r) * 16 + xoff + j);
                 sad = (int)__builtin_amdgcn_sad_u8(ref, e, (uint32_t)sad);
                 const int rsum = (int)__builtin_amdgcn_sad_u8(ref, 0u, 0u), esum = (int)__builtin_amdgcn_sad_u8(e, 0u, 0u);
                 const int k = (r >= sub ? 2 : 0) + (j >= sub ? 1 : 0);
