@@ -129,11 +129,10 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
      * source pixels and the RD decision's neighbourhood in prim_mb_fetch): one memory round trip on the macroblock chain */
     const int top = L->mb_xy - F.mb_w;
     const int nb = (mb_y > 0 ? NB_TOP : 0) | (mb_x > 0 ? NB_LEFT : 0) | (mb_x < F.mb_w - 1 && mb_y > 0 ? NB_TOPRIGHT : 0) | (mb_x > 0 && mb_y > 0 ? NB_TOPLEFT : 0);
-    int t_top = -1, t_left = -1, t_tr = -1, t_tl = -1;
-    if (nb & NB_TOP) t_top = NB_LD8(&F.mb_type[top]);
-    if (nb & NB_LEFT) t_left = NB_LD8(&F.mb_type[L->mb_xy - 1]);
-    if (nb & NB_TOPRIGHT) t_tr = NB_LD8(&F.mb_type[top + 1]);
-    if (nb & NB_TOPLEFT) t_tl = NB_LD8(&F.mb_type[top - 1]);
+    /* (unconditional loads: a neighbour that does not exist reads this macroblock's own slot and is ignored -- a load inside an `if`
+     * is a branch of its own with its own s_waitcnt, i.e. one memory round trip per neighbour instead of one for all) */
+    int t_top = NB_LD8(&F.mb_type[(nb & NB_TOP) ? top : L->mb_xy]), t_left = NB_LD8(&F.mb_type[(nb & NB_LEFT) ? L->mb_xy - 1 : L->mb_xy]);
+    int t_tr = NB_LD8(&F.mb_type[(nb & NB_TOPRIGHT) ? top + 1 : L->mb_xy]), t_tl = NB_LD8(&F.mb_type[(nb & NB_TOPLEFT) ? top - 1 : L->mb_xy]);
     const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
     const int b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
     const int t4 = (4 * (mb_y - 1) + 3) * s4 + 4 * mb_x, t8 = (2 * (mb_y - 1) + 1) * s8 + 2 * mb_x;
@@ -145,11 +144,15 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
         else if (i <= 4) { ok = nb & NB_TOP; c8 = SCAN8_0 - 8 + (i - 1); m4 = t4 + (i - 1); r8 = t8 + ((i - 1) >> 1); }
         else if (i == 5) { ok = nb & NB_TOPRIGHT; c8 = SCAN8_0 + 4 - 8; m4 = t4 + 4; r8 = t8 + 2; }
         else { ok = nb & NB_LEFT; c8 = SCAN8_0 - 1 + 8 * (i - 6); m4 = b4 - 1 + (i - 6) * s4; r8 = b8 - 1 + ((i - 6) >> 1) * s8; }
-        nb_c8[NB_SLOT(i)] = ok ? c8 : -1; nb_w[NB_SLOT(i)] = 0; nb_r[NB_SLOT(i)] = -2;
-        if (ok) { nb_w[NB_SLOT(i)] = NB_LD32(&F.mv[2 * m4]); nb_r[NB_SLOT(i)] = NB_LD8(&F.ref8[r8]); }
+        nb_c8[NB_SLOT(i)] = ok ? c8 : -1;
+        nb_w[NB_SLOT(i)] = NB_LD32(&F.mv[2 * (ok ? m4 : b4)]); nb_r[NB_SLOT(i)] = NB_LD8(&F.ref8[ok ? r8 : b8]);
     }
     prim_mb_fetch(F, mb_x, mb_y, nb, rd, pf);
     /* ---- from here on the loaded values are used */
+    if (!(nb & NB_TOP)) t_top = -1;
+    if (!(nb & NB_LEFT)) t_left = -1;
+    if (!(nb & NB_TOPRIGHT)) t_tr = -1;
+    if (!(nb & NB_TOPLEFT)) t_tl = -1;
     L->neighbour = nb;
     L->type_top = t_top; L->type_left = t_left; L->type_topright = t_tr; L->type_topleft = t_tl;
     PCAMV_WAVE_SYNC();

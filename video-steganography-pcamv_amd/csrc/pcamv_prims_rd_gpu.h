@@ -39,30 +39,30 @@ __device__ __forceinline__ void prim_mb_fetch(const FrameDev &F, int mb_x_, int 
     }
     P.role = 0; P.b0 = P.b1 = 0; P.s0 = P.s1 = P.t0 = P.t1 = P.t2 = P.t3 = 0;
     if (!rd) return;
-    if (lane < 16) {
-        const int k = lane & 7, is_left = lane >> 3;
-        P.role = 0x80;
-        if (is_left ? (nb & NB_LEFT) : (nb & NB_TOP)) P.role = (uint8_t)NB_LD8(&F.nb_nz[(is_left ? xy - 1 : top) * 16 + 8 * is_left + k]);
-    } else if (lane < 24) {
-        const int k = lane - 16, is_left = k >> 2;
-        if (is_left ? (nb & NB_LEFT) : (nb & NB_TOP)) P.role = NB_LD32(&F.nb_mvd[((is_left ? xy - 1 : top) * 8 + k) * 2]);
-    } else if (lane == 24) { if (nb & NB_TOP) P.role = (uint32_t)(int)(int16_t)NB_LD16(&F.nb_cbp[top]); }
-    else if (lane == 25) { if (nb & NB_LEFT) P.role = (uint32_t)(int)(int16_t)NB_LD16(&F.nb_cbp[xy - 1]); }
+    /* every lane makes all three loads (its role's from the neighbour, the others' from this macroblock's own slots, ignored) and keeps
+     * its role's result: loads inside the role branches each waited for their own data -- a round trip per role */
+    {
+        const int k8 = lane & 7, l8 = (lane >> 3) & 1, ok8 = lane < 16 && (l8 ? (nb & NB_LEFT) : (nb & NB_TOP));
+        const int k32 = (lane - 16) & 7, l32 = k32 >> 2, ok32 = lane >= 16 && lane < 24 && (l32 ? (nb & NB_LEFT) : (nb & NB_TOP));
+        const int ok16 = (lane == 24 && (nb & NB_TOP)) || (lane == 25 && (nb & NB_LEFT));
+        const uint32_t v8 = (uint8_t)NB_LD8(&F.nb_nz[(ok8 ? (l8 ? xy - 1 : top) : xy) * 16 + 8 * l8 + k8]);
+        const uint32_t v32 = NB_LD32(&F.nb_mvd[((ok32 ? (l32 ? xy - 1 : top) : xy) * 8 + k32) * 2]);
+        const uint32_t v16 = (uint32_t)(int)(int16_t)NB_LD16(&F.nb_cbp[ok16 ? (lane == 24 ? top : xy - 1) : xy]);
+        P.role = lane < 16 ? (ok8 ? v8 : 0x80u) : ok32 ? v32 : ok16 ? v16 : 0u;
+    }
     /* borders: luma 25 + 16, chroma 2 x (9 + 8) = 75 bytes, agent-scope loads (the neighbours stored them write-through) */
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const int i = lane + 64 * r;
-        int v = 0;
-        if (i < 75) {
-            int c, is_left, k;
-            if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
-            else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
-            const int w = c ? 8 : 16, pw = c ? F.w >> 1 : F.w, x0 = mb_x * w, y0 = mb_y * w;
-            const uint8_t *pl = c == 0 ? F.rec[0] : c == 1 ? F.rec[1] : F.rec[2];
-            if (is_left) { if (mb_x > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 + k) * pw + x0 - 1); }
-            else if (mb_y > 0) v = (uint8_t)NB_LD8((const int8_t *)pl + (size_t)(y0 - 1) * pw + clip3i(x0 + k, 0, pw - 1));
-        }
-        if (r == 0) P.b0 = v; else P.b1 = v;
+        const int i = imin(lane + 64 * r, 74);
+        int c, is_left, k;
+        if (i < 41) { c = 0; is_left = i >= 25; k = is_left ? i - 25 : i - 1; }
+        else { const int j = (i - 41) % 17; c = 1 + (i - 41) / 17; is_left = j >= 9; k = is_left ? j - 9 : j - 1; }
+        const int w = c ? 8 : 16, pw = c ? F.w >> 1 : F.w, x0 = mb_x * w, y0 = mb_y * w;
+        const uint8_t *pl = c == 0 ? F.rec[0] : c == 1 ? F.rec[1] : F.rec[2];
+        const bool ok = lane + 64 * r < 75 && (is_left ? mb_x > 0 : mb_y > 0);
+        const size_t o = !ok ? (size_t)y0 * pw + x0 : is_left ? (size_t)(y0 + k) * pw + x0 - 1 : (size_t)(y0 - 1) * pw + clip3i(x0 + k, 0, pw - 1);
+        const int v = (uint8_t)NB_LD8((const int8_t *)pl + o);
+        if (r == 0) P.b0 = ok ? v : 0; else P.b1 = ok ? v : 0;
     }
     if (F.b_cabac) {
         const uint32_t *src = (const uint32_t *)(xy == 0 ? F.cabac_init : F.cabac);
