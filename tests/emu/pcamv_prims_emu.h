@@ -69,6 +69,7 @@ static inline void emu_mc_chroma(const FrameDev &F, uint8_t *dst, int ds, int pl
         dst[y * ds + x] = (cA * s[y * F.cstride + x] + cB * s[y * F.cstride + x + 1] + cC * s[(y + 1) * F.cstride + x] + cD * s[(y + 1) * F.cstride + x + 1] + 32) >> 6;
 }
 /* all listed candidates: pixel metric (+ MV bits) (+ chroma), costs to L->ccost, first minimum returned */
+static inline int prim_mv_cost(const FrameDev &F, int d) { return (int)F.cost_mv[d]; }       /* entry d = mv - mvp of the MV-bit table (centre pointer) */
 static inline EvalRes prim_eval_list(const FrameDev &F, MBLocal *L, const uint8_t *enc, int ip, int xoff, int yoff, int n, int flags, int mvp0, int mvp1)
 {
     EvalRes r = {PCAMV_COST_MAX, -1};

@@ -391,7 +391,7 @@ static int ensure_qp(pcamv_ctx *c, int qp)
         int16_t *h = (int16_t *)malloc(PCAMV_COST_MV_LEN * sizeof(int16_t));
         if (!h) return fail(c, PCAMV_ENOMEM, "cost table");
         pcamv_build_cost_mv(qp, h);
-        hipError_t e = dalloc(&c->d_cost_mv[qp], (size_t)PCAMV_COST_MV_LEN);
+        hipError_t e = dalloc(&c->d_cost_mv[qp], (size_t)PCAMV_COST_MV_LEN + 1);      /* + 1: prim_mv_cost fetches the dword that holds an entry */
         if (e == hipSuccess) e = hipMemcpy(c->d_cost_mv[qp], h, PCAMV_COST_MV_LEN * sizeof(int16_t), hipMemcpyHostToDevice);
         free(h);
         if (e != hipSuccess) return fail(c, PCAMV_EHIP, "cost table upload: %s", hipGetErrorString(e));

@@ -206,8 +206,8 @@ PCAMV_DEV int hex4_y(int j) { return nib64(0x1017876543223456ull, j) - 4; }     
 PCAMV_DEV int range_mul_of(int mvd_ctx, int sad_ctx) { return nib64(0x6544544444434433ull, 4 * mvd_ctx + sad_ctx); } /* {3,3,4,4},{3,4,4,4},{4,4,4,5},{4,4,5,6} */
 PCAMV_DEV int size_shift_of(int ip) { return nib32(0x4332110u, ip); }                              /* {0,1,1,2,3,3,4} */
 
-#define MVCOSTX(v) ((int)F.cost_mv[(v) - me->mvp[0]])
-#define MVCOSTY(v) ((int)F.cost_mv[(v) - me->mvp[1]])
+#define MVCOSTX(v) prim_mv_cost(F, (v) - me->mvp[0])        /* one (wave-uniform) entry of the MV-bit table */
+#define MVCOSTY(v) prim_mv_cost(F, (v) - me->mvp[1])
 
 PCAMV_DEV EvalRes eval_cands(const FrameDev &F, MBLocal *L, MEState *me, const uint8_t *enc, int n, int flags)
 {

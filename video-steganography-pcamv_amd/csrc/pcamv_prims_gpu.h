@@ -108,6 +108,16 @@ __device__ __forceinline__ uint64_t gld8(gp8 base, uint32_t off) { return *(cons
 /* entry i of the MV-bit table (int16): scalar table base + a 32-bit byte offset (a pointer + index form makes the compiler do
  * 64-bit vector address arithmetic in every list pass) */
 __device__ __forceinline__ int gld_cost(gp8 tab, uint32_t i) { return (int)*(const __attribute__((address_space(1))) int16_t *)(tab + (i << 1)); }
+/* one wave-uniform entry of the MV-bit table for the control code (the cost of the search's current best MV, of its start point): a
+ * SCALAR load (236 cycles on average under load against 580 for a vector load; the table is constant during a launch).  d = mv - mvp,
+ * relative to the table's centre; the containing dword is fetched and the half picked */
+__device__ __forceinline__ int prim_mv_cost(const FrameDev &F, int d)
+{
+    const int i = rfl(d) + PCAMV_COST_MV_CENTRE;
+    const __attribute__((address_space(4))) uint32_t *t = (const __attribute__((address_space(4))) uint32_t *)(F.cost_mv - PCAMV_COST_MV_CENTRE);
+    const uint32_t w = t[i >> 1];
+    return (int)(int16_t)(w >> (16 * (i & 1)));
+}
 /* luma planes are strips (pcamv_common.h): the x part of a pixel's byte offset; the y part is y * PCAMV_LROW.  4 bytes from there
  * (and from x + 1: the repeated columns) lie in one strip */
 /* 32-bit integer multiplies run at a quarter of the VALU rate on this chip; where both factors are known to stay below 2^24
