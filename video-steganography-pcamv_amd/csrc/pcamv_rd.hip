@@ -14,7 +14,7 @@
  *     the fastest macroblock.  Used while the chains are few (G <= 2 x CUs): G=64 874 ms per 1080p step, 512: 943 ms = 4.43 M MB/s;
  *   - "hi", 4 waves per SIMD at 128 VGPRs, nothing spilled (the lane number is laundered, pcamv_prims_gpu.h LANE(): with the
  *     lane == k flags hoisted it spilled 149 registers and every reload was a memory round trip in front of its use):
- *     G=1024 7.77 M MB/s (lo: 6.84 M -- no free wave left for the RCA steps), G=4096 18.9 M.
+ *     G=1024 7.77 M MB/s (lo: 6.84 M -- no free wave left for the RCA steps), G=4096 19.1 M.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
