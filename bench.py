@@ -19,9 +19,12 @@ collective.  --strong: --gops is the size of ONE fixed set of GOPs, sharded roun
 after the timed region payloads are gathered to rank 0 in GOP order with tensor collectives over RCCL.
 
 Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, `roofline` for the dominant kernel, `cpu_baseline` (the
-oracle port on a bounded 1080p sample + the reference itself, oracle/_ref, on CIF with the port beside it), and -- labelled
-extras, never `value` -- `pcie_inclusive` (the same steps with every frame's pictures uploaded and its results downloaded,
-overlapped with the compute) and `g_sweep` (throughput against the number of GOPs in flight).
+oracle port on a bounded 1080p sample + the reference itself, oracle/_ref, on CIF with the port beside it), `parity_at_scale`
+(after the timed loop: the first GOP of every XCD queue against the port run over the same chained frames, every GOP of a content
+class against that class's first GOP), and -- labelled extras, never `value` -- `pcie_inclusive` (the same steps with every
+frame's pictures uploaded and its results downloaded, overlapped with the compute), `g_sweep` (throughput against the number of
+GOPs in flight), `clip_600` (BASELINE config 3's 600 frames as closed GOPs of --keyint frames: wall time of the whole clip) and
+`config4_literal` (8 closed GOPs).
 """
 import argparse
 import hashlib
@@ -30,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -56,7 +60,11 @@ def parse_args():
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--emrate", type=float, default=0.5)
     ap.add_argument("--open-loop", action="store_true", help="pass 1 only: no pass 2 / loop filter, the reference is the previous source frame")
-    ap.add_argument("--host-io-steps", type=int, default=2, help="steps of the PCIe-inclusive pipeline (0 = skip; rank 0, N=1 only)")
+    ap.add_argument("--host-io-steps", type=int, default=6, help="steps of the PCIe-inclusive pipeline (0 = skip; rank 0, N=1 only)")
+    ap.add_argument("--classes", type=int, default=64, help="distinct content classes: GOP g starts at frame g mod classes of a synthetic clip that long")
+    ap.add_argument("--parity-gops", type=int, default=8, help="GOPs compared with the CPU port after the timed loop (the first of every XCD queue; 0 = skip)")
+    ap.add_argument("--clip-keyints", default="30,8", help="keyint values of the 600-frame clip block ('' = skip; rank 0, N=1 only)")
+    ap.add_argument("--clip-frames", type=int, default=600)
     ap.add_argument("--g-sweep", default="1,8,20,64,256", help="GOP counts of the low-G sweep ('' = skip; rank 0, N=1 only)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="1080p P frames timed for the CPU baseline (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-cif-frames", type=int, default=200, help="CIF P frames timed through the reference itself (oracle/_ref) and through the port (0 = skip)")
@@ -73,10 +81,11 @@ def self_launch(args):
 
 
 class Gops:
-    """closed-GOP pipelines on one device: contexts + batch + the step function.  phases[k] = position of GOP k in the clip cycle"""
+    """closed-GOP pipelines on one device: contexts + batch + the step function.  phases[k] = frame of the (cyclic) clip GOP k starts at:
+    the reference of its step 0 is that frame (standing in for the GOP's I picture), the source of its step t is frame phases[k] + t + 1"""
 
     def __init__(self, pcamv_amd, params, dframes, phases, device, closed_loop):
-        self.dframes, self.closed, self.phases = dframes, closed_loop, list(phases)
+        self.dframes, self.closed, self.phases = dframes, closed_loop, [int(ph) % len(dframes) for ph in phases]
         self.encs = [pcamv_amd.Encoder(params, device=device) for _ in self.phases]
         self.batch = pcamv_amd.Batch(self.encs)
         if closed_loop:
@@ -90,6 +99,9 @@ class Gops:
             ph = self.phases[k]
             if self.closed and self.started:     # reference = this GOP's own deblocked reconstruction of the previous step, chained MV field
                 enc.set_ref_device(self.recon[k][0], self.recon[k][1], self.recon[k][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
+            elif self.closed:                    # a GOP's first P frame: the reference is an I picture, no motion field behind it
+                a = self.dframes[(t + ph) % nfr]
+                enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), 0, 0)
             else:
                 a = self.dframes[(t + ph) % nfr]
                 enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
@@ -159,7 +171,9 @@ def main():
     if G < 1:
         sys.exit(f"rank {rank}: no GOP to run (--strong --gops {args.gops} over {world} ranks)")
 
-    nfr = 6                                                  # synthetic clip (SURVEY 8(d) generator): a few distinct frames, cycled
+    # synthetic clip (SURVEY 8(d) generator) of --classes frames, cycled; GOP g starts at frame g mod classes, so --classes
+    # content classes with different source pictures and motion histories are in flight (round 2 cycled 6 frames: 683 GOPs per class)
+    nfr = max(2, args.classes)
     clip = make_clip(W, H, nfr, seed=13)
     dframes = [[torch.from_numpy(pl).to(dev) for pl in fr] for fr in clip]
     run = Gops(pcamv_amd, p, dframes, mine, local, closed_loop)
@@ -212,17 +226,75 @@ def main():
     n_diag = (W // 16) + 2 * (H // 16 - 1)
     flow = dom.startswith("k_analyse_flow")
 
-    # the embedded payload comes back out of the final motion vectors (first GOP of this rank)
-    mbs, emb = run.encs[0].fetch_results(want_embed=True)
+    # the embedded payload comes back out of the final motion vectors (the first GOPs of this rank: one per XCD queue)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
     from helpers import carrier_lsbs
-    ber = None
-    if emb["m"] > 0:
-        if emb["stc_ok"] != 1:
-            sys.exit("bench.py: the syndrome-trellis embedding of GOP 0 failed")
-        final = run.encs[0].final_mvs(mbs)
-        ext = pcamv_amd.stc_extract(carrier_lsbs(final), emb["m"])
-        ber = float((ext != emb["message"]).mean())
+    T_done = args.warmup + args.steps
+    n_chk = max(1, min(args.parity_gops if args.parity_gops > 0 else 1, G, 8))
+    ber, ber_bits, chk = None, 0, []
+    for k in range(n_chk):
+        mbs_k, emb_k = run.encs[k].fetch_results(want_embed=True)
+        rec_k = run.encs[k].fetch_recon() if closed_loop else None
+        chk.append((mbs_k, emb_k, rec_k))
+        if emb_k["m"] > 0:
+            if emb_k["stc_ok"] != 1:
+                sys.exit(f"bench.py: the syndrome-trellis embedding of GOP {k} failed")
+            ext = pcamv_amd.stc_extract(carrier_lsbs(run.encs[k].final_mvs(mbs_k)), emb_k["m"])
+            ber = (0.0 if ber is None else ber) + float((ext != emb_k["message"]).sum())
+            ber_bits += int(emb_k["m"])
+    if ber is not None:
+        ber /= ber_bits
+    mbs, emb = chk[0][0], chk[0][1]
+
+    # ---- parity at scale: what the timed loop computed (4 waves per SIMD, eight queues, work stealing, second-pass tasks of 8
+    # macroblocks) against the CPU port on the same chained frames.  The port runs in threads (ctypes releases the GIL) while the
+    # extras below keep the GPU busy; joined before the CPU baseline is timed.
+    parity, par_threads, par_res = None, [], {}
+    if rank == 0 and world == 1 and args.parity_gops > 0 and closed_loop and T_done > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        op_par = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac)
+        assert (op_par.i_psy_rd, op_par.i_chroma_qp_offset) == (p.i_psy_rd, p.i_chroma_qp_offset)
+
+        def port_gop(k):
+            t_c = time.perf_counter()
+            o = orc.Oracle(op_par)
+            ph, prev, ref = run.phases[k], (None, None), clip[run.phases[k] % nfr]
+            for t in range(T_done):
+                o.set_fenc(*clip[(t + ph + 1) % nfr])
+                o.set_ref(*ref, *prev)
+                m_o, _ = o.analyse_pframe(args.qp, 1)
+                e_o = o.embed_pframe(m_o, args.emrate)
+                fo, _, _, ref, _ = o.pass2_pframe(args.qp, m_o, (np.asarray(e_o["flip"]) == 1).astype(np.uint8))
+                prev = helpers.mv_field(fo["mv"], W // 16, H // 16)
+            o.close()
+            par_res[k] = (m_o, e_o, ref, time.perf_counter() - t_c)
+
+        par_threads = [threading.Thread(target=port_gop, args=(k,)) for k in range(n_chk)]
+        for th in par_threads:
+            th.start()
+        # every GOP of a content class has seen the same pictures and the same message stream: its records and flip map must be
+        # those of the class's first GOP (compared on the device, all GOPs)
+        mb_bytes_, flip_bytes_ = n_mb * MB_RECORD, 16 * n_mb
+        d_all = torch.empty((G, mb_bytes_ + flip_bytes_), dtype=torch.uint8, device=dev)
+        run.batch.copy_results_async(d_all.data_ptr(), mb_bytes_ + flip_bytes_, d_all.data_ptr() + mb_bytes_, mb_bytes_ + flip_bytes_, stream.cuda_stream)
+        torch.cuda.synchronize()
+        first_of = {}
+        idx_first = torch.tensor([first_of.setdefault(ph, k) for k, ph in enumerate(run.phases)], device=dev)
+        n_car = torch.tensor([0], device=dev)
+        same = True
+        for lo in range(0, G, 256):
+            hi = min(G, lo + 256)
+            same = same and bool((d_all[lo:hi, :mb_bytes_] == d_all[idx_first[lo:hi], :mb_bytes_]).all().item())
+        # (flip maps: the first `n carriers` bytes are meaningful, the rest is zeroed by the embedding stage)
+        for lo in range(0, G, 256):
+            hi = min(G, lo + 256)
+            same = same and bool((d_all[lo:hi, mb_bytes_:] == d_all[idx_first[lo:hi], mb_bytes_:]).all().item())
+        del d_all, n_car
+        if not same:
+            sys.exit("bench.py: GOPs of the same content class ended the timed loop with different records / flip maps")
+        parity = {"gops_identical_within_class": True, "content_classes": len(first_of), "gops": G}
 
     # N > 1: per-rank summary to every rank, and (--strong) the payloads of the set's first GOPs to rank 0 in GOP order;
     # tensor collectives over RCCL, after the timed region
@@ -253,18 +325,30 @@ def main():
     achieved = B_SEARCH * mbs_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM-side traffic and SIMD issue counters of the dominant kernel: from the committed PMC summaries of this same command
     # (tools/dbg/pmc.sh + pmc_profiles.py; separate rocprofv3 passes), not measured in this run -- labelled with their source
-    traffic, traffic_src, issue = None, None, None
+    traffic, traffic_src, issue, valu_issue = None, None, None, None
     tag = "rd" if dom == "k_analyse_flow_rd" else "base"
-    tfile = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{tag}.json")
-    if os.path.exists(tfile):
-        with open(tfile) as fh:
-            tj = json.load(fh)
+
+    def profile_json(kind):
+        for rnd in ("r03", "r02"):
+            f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{kind}_{tag}.json")
+            if os.path.exists(f):
+                with open(f) as fh:
+                    return json.load(fh), os.path.relpath(f, ROOT)
+        return None, None
+
+    tj, tname = profile_json("traffic")
+    if tj:
         traffic = tj["bytes_per_mb"] * mbs_per_launch
-        traffic_src = f"profiles/r02_pmc_traffic_{tag}.json ({tj['gops']} GOPs in flight; {tj['bytes_per_mb']:.0f} B per macroblock scaled to this launch)"
-    sfile = os.path.join(ROOT, "profiles", f"r02_pmc_sq_summary_{tag}.json")
-    if os.path.exists(sfile):
-        with open(sfile) as fh:
-            issue = dict(json.load(fh)["summary"], source=f"profiles/r02_pmc_sq_summary_{tag}.json (committed profile of this command, not this run)")
+        traffic_src = f"{tname} ({tj['gops']} GOPs in flight; {tj['bytes_per_mb']:.0f} B per macroblock scaled to this launch)"
+    sj, sname = profile_json("sq_summary")
+    if sj:
+        issue = dict(sj["summary"], source=f"{sname} (committed profile of this command, not this run)")
+        # what bounds the kernel: VALU instructions per macroblock (committed counters) x the macroblocks of this launch, against what
+        # the chip's 1024 SIMDs issue in the launch's measured duration (one wave64 VALU instruction per 4 cycles at 2.4 GHz)
+        if avg_ms > 0 and flow:
+            valu_issue = {"frac": sj["summary"]["instructions_per_mb"]["VALU"] * mbs_per_launch / (1024 * 2.4e9 / 4 * avg_ms * 1e-3),
+                          "valu_per_mb": sj["summary"]["instructions_per_mb"]["VALU"], "lanes_active_of_64": sj["summary"].get("valu_active_lanes_of_64"),
+                          "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction", "source": sname}
     out = {
         "metric": "1080p macroblocks/s (embed on)", "value": value, "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -272,9 +356,9 @@ def main():
         "config": {"workload": f"BASELINE config 3: {W}x{H} synthetic I420, --me {args.me} --subme {args.subme} --qp {args.qp} --emrate {args.emrate}"
                                f"{' --no-cabac' if args.no_cabac else ''}, " + ("closed loop (pass 2 + loop filter on the GPU)" if closed_loop else "open-loop reference")
                                + (f", {args.gops} closed GOPs in total sharded over the ranks" if args.strong else f", {args.gops} closed GOPs in flight per GPU"),
-                   "mb_per_frame": n_mb, "gops_per_gpu": G, "frames_per_step": total_gops,
+                   "mb_per_frame": n_mb, "gops_per_gpu": G, "frames_per_step": total_gops, "content_classes": min(nfr, total_gops),
                    "value_is": "inputs resident in HBM when the timed region starts; pcie_inclusive is the host-fed pipeline"},
-        "extracted_payload_BER": ber,
+        "extracted_payload_BER": ber, "BER_checked": {"gops": n_chk, "bits": ber_bits},
         "carriers_per_frame": int(emb["n"]), "bits_per_frame": int(emb["m"]),
         "hbm_algorithmic_GBps_whole_path": (B_WHOLE if closed_loop else B_WHOLE / 2) * value / 1e9,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -282,7 +366,7 @@ def main():
                      "avg_launch_ms": avg_ms, "launches_timed": n_launch, "mbs_per_launch": mbs_per_launch, "bytes_per_mb": B_SEARCH,
                      "bound_note": "byte/integer work priced against HBM as the contract asks; what limits this kernel is not bandwidth but instruction "
                                    "issue (at 4096 chains the VALU is ~83 % busy; with few chains, the dependent chain inside a macroblock): issue_counters, DESIGN.md 4a",
-                     "issue_counters": issue},
+                     "issue_counters": issue, "valu_issue_frac": valu_issue},
     }
     if gathered is not None:
         out["gathered_payloads"] = gathered
@@ -304,6 +388,7 @@ def main():
         up_done = [torch.cuda.Event() for _ in range(2)]
         step_done = [torch.cuda.Event() for _ in range(2)]
         down_done = torch.cuda.Event()
+        down_t = [torch.cuda.Event(enable_timing=True) for _ in range(args.host_io_steps)]     # step k's results are in host memory
 
         def upload(t, buf):
             with torch.cuda.stream(copy_st):
@@ -334,18 +419,25 @@ def main():
                 copy_st.wait_event(step_done[cur])
                 h_out.copy_(d_out, non_blocking=True)
                 down_done.record(copy_st)
+                down_t[k].record(copy_st)
         torch.cuda.synchronize()
         dth = time.perf_counter() - t1
+        nio = args.host_io_steps
+        steady_ms = down_t[0].elapsed_time(down_t[nio - 1]) / (nio - 1) if nio > 1 else dth * 1e3
         t_next += args.host_io_steps
         got = np.frombuffer(h_out[0, :mb_bytes].numpy().tobytes(), dtype=np.uint8)
         chk = np.asarray(run.encs[0].fetch_results(want_embed=False)[0]).view(np.uint8).reshape(-1)
         if not np.array_equal(got, chk):
             sys.exit("bench.py: the records downloaded by the overlapped pipeline differ from the blocking fetch")
-        out["pcie_inclusive"] = {"value": G * n_mb * args.host_io_steps / dth, "unit": "MB/s", "ms_per_step": dth / args.host_io_steps * 1e3,
-                                 "steps": args.host_io_steps, "h2d_bytes_per_frame": row_in, "d2h_bytes_per_frame": row_out,
+        out["pcie_inclusive"] = {"value": G * n_mb / (steady_ms * 1e-3), "unit": "MB/s", "ms_per_step": steady_ms,
+                                 "steps": nio, "whole_pipeline_ms": dth * 1e3, "fill_and_drain_ms": dth * 1e3 - steady_ms * (nio - 1),
+                                 "value_incl_fill_and_drain": G * n_mb * nio / dth,
+                                 "h2d_bytes_per_frame": row_in, "d2h_bytes_per_frame": row_out,
                                  "note": "extra, never `value`: source pictures host->device from pinned memory and records + flip maps device->host "
                                          "(pcamv_gpu_batch_copy_results_async) on a copy stream, double-buffered, overlapped with the compute; "
-                                         "the pipeline's fill and drain are inside the timed region"}
+                                         "value / ms_per_step = the steady state (HIP events: arrival of one step's results in host memory to the "
+                                         "next one's, averaged over the pipeline's steps); fill_and_drain_ms = the first step's upload + compute + "
+                                         "download that nothing overlaps"}
         del dstage, d_out, h_out, hsrc
 
     # ---- throughput against the number of GOPs in flight (extra): a frame's macroblocks form one chain, so few GOPs = few busy waves
@@ -382,6 +474,62 @@ def main():
             d = (time.perf_counter() - ts) / 5
             out["other_workloads"] = [{"workload": f"{W}x{H} --me {args.me} --subme 5, 256 GOPs in flight, same closed loop", "value": 256 * n_mb / d, "unit": "MB/s", "ms_per_step": d * 1e3}]
             sub.close()
+
+    # ---- BASELINE config 3 as a clip (extra): --clip-frames frames cut into closed GOPs of keyint frames (1 I + keyint - 1 P), all GOPs in
+    # flight on this GPU; wall time until the clip's last P frame is done (every step's ramp included).  The I pictures are not part of
+    # the path (the source picture stands in for their reconstruction) and of no time here.
+    if solo and args.clip_keyints and closed_loop:
+        blocks = []
+        for K in [int(x) for x in args.clip_keyints.split(",") if x]:
+            n_g = max(1, args.clip_frames // K)
+            if K < 2:
+                continue
+            sub = Gops(pcamv_amd, p, dframes, [g * K for g in range(n_g)], local, closed_loop)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for t in range(K - 1):
+                sub.step(t, args.qp, args.emrate, stream.cuda_stream)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - ts
+            blocks.append({"keyint": K, "gops": n_g, "p_frames": n_g * (K - 1), "wall_s": d, "value": n_g * (K - 1) * n_mb / d, "unit": "MB/s"})
+            sub.close()
+        out["clip_600"] = {"frames": args.clip_frames, "runs": blocks,
+                           "note": "extra: P-frame macroblocks / wall time of the whole clip on one GPU, no warm-up (context creation outside); "
+                                   "keyint 30 = 20 chains for 29 steps: a CABAC frame is one serial chain, so few GOPs = few busy waves"}
+    # ---- BASELINE config 4 read literally (extra): 8 closed GOPs.  On one GPU that is 8 chains in flight; on 8 GPUs one chain each --
+    # the g_sweep's 1-GOP time predicts what 8 GPUs would take for the same 8 GOPs (nothing multi-GPU is measured here)
+    if solo and closed_loop and "g_sweep" in out:
+        by_g = {e["gops"]: e for e in out["g_sweep"]}
+        if 1 in by_g and 8 in by_g:
+            out["config4_literal"] = {"gops": 8, "one_gpu_ms_per_step": by_g[8]["ms_per_step"], "one_gpu_value": by_g[8]["value"], "unit": "MB/s",
+                                      "eight_gpus_predicted_ms_per_step": by_g[1]["ms_per_step"],
+                                      "predicted_scaling_1_to_8": by_g[8]["ms_per_step"] / by_g[1]["ms_per_step"],
+                                      "note": "prediction from this run's g_sweep, not a measurement: with 8 GOPs there are 8 chains whatever the number "
+                                              "of GPUs; the >= 6x scaling target needs >= 8 x the GOPs one GPU saturates with (weak scaling, the default of --gpus N)"}
+
+    # ---- parity at scale, second half: the port's threads have been running beside the extras above
+    if par_threads:
+        for th in par_threads:
+            th.join()
+        for k in range(n_chk):
+            if k not in par_res:
+                sys.exit(f"bench.py: the CPU port of GOP {k} did not finish")
+            m_o, e_o, rec_o, _ = par_res[k]
+            mbs_k, emb_k, rec_k = chk[k]
+            for f in mbs_k.dtype.names:
+                if not np.array_equal(mbs_k[f], m_o[f]):
+                    sys.exit(f"bench.py: parity at scale: GOP {k} field {f} differs from the CPU port after {T_done} chained steps")
+            if not np.array_equal(np.asarray(emb_k["flip"]), np.asarray(e_o["flip"])) or not np.array_equal(np.asarray(emb_k["message"]), np.asarray(e_o["message"])):
+                sys.exit(f"bench.py: parity at scale: GOP {k}: flip map / message differ from the CPU port")
+            for a, b in zip(rec_k, rec_o):
+                if not np.array_equal(a, b):
+                    sys.exit(f"bench.py: parity at scale: GOP {k}: deblocked picture differs from the CPU port")
+        parity.update(gops_vs_port=list(range(n_chk)), chained_steps=T_done, ok=True,
+                      compared="pass-1 records, flip map, message and deblocked planes of the timed loop's last step (each the product of all "
+                               "chained steps before it) against oracle/pcamv_oracle.c run over the same frames; GOP k lives in XCD queue k & 7",
+                      port_cpu_s=round(sum(par_res[k][3] for k in range(n_chk)), 1), port_threads=n_chk)
+    if parity is not None:
+        out["parity_at_scale"] = parity
 
     # ---- CPU baseline (rank 0, N=1): the port on a bounded sample of the same 1080p workload; the reference itself on CIF
     if solo and args.cpu_frames > 0:
@@ -444,8 +592,12 @@ def main():
             tport = port_run(cw, ch, args.cpu_cif_frames, cclip, mvr)
             cb["ref_cif"] = {"value": args.cpu_cif_frames * cn / tref, "unit": "MB/s", "cores": 1, "kind": "reference",
                              "port_on_same_sample": args.cpu_cif_frames * cn / tport,
+                             "path": "C path (cpu = 0: no x86 SIMD -- no assembler in this image), 1 thread, its stc_embed call excluded",
                              "sample": f"{args.cpu_cif_frames} CIF P frames, same options, through oracle/_ref (the reference's sources, gcc -O3): analysis"
                                        f"{' + second pass' if closed_loop else ''} ({tref:.1f} s); the port's figure beside it also contains its embedding ({tport:.1f} s)"}
+            if "clip_600" in out:
+                for b_ in out["clip_600"]["runs"]:
+                    b_["x_ref_cif"] = b_["value"] / cb["ref_cif"]["value"]
         out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out))

@@ -182,6 +182,14 @@ int pcamv_gpu_parse_pslice_cabac(const uint8_t *slice_data, size_t len, int mb_w
 /* the same for a CAVLC-coded P slice (--no-cabac): slice_data = from the first mb_skip_run to the rbsp trailing bits, as
  * encoder/cavlc.c writes them (mb_skip_run, mb_type, sub_mb_type, mvd, coded_block_pattern, mb_qp_delta, residual_block_cavlc) */
 int pcamv_gpu_parse_pslice_cavlc(const uint8_t *slice_data, size_t len, int mb_w, int mb_h, pcamv_mb_t *out_mb);
+/* The same on what a stream really holds.  pcamv_gpu_nal_to_rbsp undoes x264_nal_encode (common/common.c:658-690): optional Annex-B
+ * start code, the NAL header byte (returned), emulation_prevention_three_bytes removed; rbsp must hold len bytes.  The _at forms
+ * start at bit start_bit of the RBSP, i.e. right behind a slice header of any length (the caller parses or skips the header:
+ * it depends on the SPS / PPS in use): CAVLC slice data begins at that bit, CABAC slice data after the cabac_alignment_one_bits
+ * that fill up the byte. */
+int pcamv_gpu_nal_to_rbsp(const uint8_t *nal, size_t len, uint8_t *rbsp, size_t *rbsp_len, int *nal_ref_idc, int *nal_unit_type);
+int pcamv_gpu_parse_pslice_cabac_at(const uint8_t *rbsp, size_t len, size_t start_bit, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb);
+int pcamv_gpu_parse_pslice_cavlc_at(const uint8_t *rbsp, size_t len, size_t start_bit, int mb_w, int mb_h, pcamv_mb_t *out_mb);
 
 /* Device-resident variants used by bench.py and the multi-frame pipeline: planes are raw
  * device pointers (hipMalloc / torch storage), tightly packed like recon[] above. */
@@ -239,6 +247,17 @@ int pcamv_gpu_kernel_time(pcamv_ctx_t *ctx, const char *kernel, double *avg_ms, 
  * satd}, each answered with {luma cost, U cost, V cost} of the uploaded fenc block against the
  * current reference at that MV (no MV-bit cost added). */
 int pcamv_gpu_block_costs(pcamv_ctx_t *ctx, int qp, int n, const int32_t *req, int32_t *out);
+
+/* Probe of the RD stage's metrics and intra predictors on caller-supplied pixels, for parity tests against reference-minted vectors
+ * (common/pixel.c:71-96 ssd, :256-358 sa8d / hadamard_ac; encoder/rdo.c:106-137 ssd_mb with the psy-RD term; encoder/analyse.c:522-549
+ * x264_mb_cache_fenc_satd; common/predict.c 16x16 / chroma 8x8 / 4x4 predictors scored with satd -- sad at subme 1 -- as the intra
+ * analysis of analyse.c:552-879 does).  n requests of 1024 bytes: source macroblock (Y 16x16 rows of 16, then 8 rows of U | V),
+ * a second macroblock in the same layout, intra borders top[3][28] ([c][3] = top-left sample, [c][4 + x]; luma 24 wide) and
+ * left[3][16], int32 avail at byte 900 (bit 0 left, bit 1 top).  out: 32 int32 per request -- 0 ssd 16x16 + 2 x 8x8 of source vs
+ * second block, 1 the same + the psy term (ssd_mb), 2 / 3 hadamard_ac 16x16 of the second block's luma (4x4 / 8x8 energies),
+ * 4 / 5 fenc_satd_sum / fenc_sa8d_sum of the source, 6..9 intra 16x16 V, H, DC (variant by avail), P, 10..13 intra chroma DC
+ * (variant), H, V, P over both planes, 14..25 the twelve 4x4 modes on block 0 (x264's I_PRED_4x4 order); unavailable = 1 << 28. */
+int pcamv_gpu_rd_probe(pcamv_ctx_t *ctx, int qp, int n, const uint8_t *req, int32_t *out);
 
 /* Diagnostics: record every block-cost evaluation {ip,xoff,yoff,mvx,mvy,flags,cost,cost2} made for
  * macroblock mb by the next analyse call (mb < 0: off); out holds 1 + 8*4000 int32, out[0] = count. */

@@ -29,6 +29,7 @@ typedef struct {
 int pcamv_glue_open( x264_t *h, pcamv_glue_t *g, int device )
 {
     pcamv_params_t gp;
+    memset( g, 0, sizeof(*g) );             /* a failed open leaves nothing for pcamv_glue_close to trip over */
     memset( &gp, 0, sizeof(gp) );
     gp.i_width  = 16 * h->sps->i_mb_width;
     gp.i_height = 16 * h->sps->i_mb_height;
@@ -50,6 +51,8 @@ int pcamv_glue_open( x264_t *h, pcamv_glue_t *g, int device )
     if( !g->mb || pcamv_gpu_open( &gp, device, &g->gpu ) < 0 )
     {
         x264_log( h, X264_LOG_ERROR, "pcamv_gpu_open failed (there is no CPU fallback)\n" );
+        x264_free( g->mb );
+        g->mb = NULL; g->gpu = NULL;
         return -1;
     }
     g->embed.cover = h->info.cover;  g->embed.rho = h->info.rho_final;  g->embed.message = h->info.message;
@@ -59,8 +62,9 @@ int pcamv_glue_open( x264_t *h, pcamv_glue_t *g, int device )
 
 void pcamv_glue_close( pcamv_glue_t *g )
 {
-    pcamv_gpu_close( g->gpu );
+    pcamv_gpu_close( g->gpu );            /* NULL after a failed open: a no-op */
     x264_free( g->mb );
+    g->gpu = NULL; g->mb = NULL;
 }
 
 /* pass 1 of a P frame: h->fref0[0] is the (deblocked, expanded) reference, h->fenc the source picture */

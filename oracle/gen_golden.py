@@ -197,6 +197,12 @@ def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, fina
     mbs, _ = r.analyse_pframe(qp)
     d = dict(width=W, height=H, qp=qp, final=int(final), cabac=cabac)
     if final:
+        # the inputs too: the GPU path runs pass 1 + embedding + pass 2 on them and must arrive at the motion a decoder reads out of
+        # this slice (tests/test_gpu_parity.py::test_final_mvs_are_what_a_decoder_reads)
+        d.update(me=refh.ME[me], subme=subme, mv_range=mvr, inter=inter & 0x31)
+        for k, nm in enumerate("yuv"):
+            d[f"ref_{nm}"] = clip[0][k]; d[f"fenc_{nm}"] = clip[1][k]
+    if final:
         o = orc.Oracle(orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter & 0x31, cabac=cabac))
         e = o.embed_pframe(mbs.view(orc.MB_DTYPE), 0.5)
         o.close()
@@ -205,8 +211,31 @@ def pslice_fixture(name, W, H, me, subme, qp, inter, seed, static, noise=6, fina
         mbs = mbs2
     data = r.slice_data()
     d.update(slice_data=np.frombuffer(data, np.uint8), type=mbs["type"], partition=mbs["partition"], sub_partition=mbs["sub_partition"], mv=mbs["mv"])
+    # the same slice data where a stream has it: behind a slice header that ends in the middle of a byte (hdr_bits of a fixed pattern
+    # stand in for it: its fields depend on the SPS / PPS, not on this path), escaped into a NAL unit by the reference's own
+    # x264_nal_encode (common/common.c:658).  CAVLC data follows the header bit for bit, CABAC data after alignment ones.
+    hdr_bits = 27 if cabac else 21
+    # (CABAC streams hardly ever contain 00 00 0x themselves: their stand-in header does, so that every fixture crosses the escaper)
+    bits = [0] * 24 + [1, 0, 1] if cabac else [(0xB5C3A7 >> (i % 24)) & 1 for i in range(hdr_bits)]
+    if cabac:
+        bits += [1] * (-len(bits) % 8)
+    bits += [(b >> (7 - i)) & 1 for b in data for i in range(8)]
+    if len(bits) % 8:                       # CAVLC: the trailing bits were written for a byte-aligned start; re-align them
+        while bits and bits[-1] == 0:
+            bits.pop()
+        bits += [0] * (-len(bits) % 8)
+    payload = np.packbits(np.array(bits, np.uint8)).copy()
+    import ctypes as C
+
+    class Nal(C.Structure):
+        _fields_ = [("i_ref_idc", C.c_int), ("i_type", C.c_int), ("i_payload", C.c_int), ("p_payload", C.c_void_p)]
+    nal = Nal(2, 1, len(payload), payload.ctypes.data)
+    dst = np.zeros(2 * len(payload) + 64, np.uint8)
+    n = C.c_int(0)
+    refh.lib().x264_nal_encode(C.c_void_p(dst.ctypes.data), C.byref(n), 1, C.byref(nal))
+    d.update(nal=dst[:n.value].copy(), nal_hdr_bits=hdr_bits, nal_escapes=int(n.value - 5 - len(payload)))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
-    print(name, len(data), "bytes of slice data,", dict(zip(*np.unique(mbs["type"], return_counts=True))))
+    print(name, len(data), "bytes of slice data,", d["nal_escapes"], "emulation prevention bytes,", dict(zip(*np.unique(mbs["type"], return_counts=True))))
 
 
 if __name__ == "__main__":

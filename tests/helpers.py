@@ -44,12 +44,12 @@ def compare_records(golden_mbs, got, what=""):
 
 
 def mv_field(mbs_mv, mbw, mbh):
-    mvf = np.zeros((mbh * 4, mbw * 4, 2), np.int16)
-    for xy in range(mbw * mbh):
-        my, mx = divmod(xy, mbw)
-        for i in range(16):
-            mvf[my * 4 + BY[i], mx * 4 + BX[i]] = mbs_mv[xy][i]
-    return mvf, np.zeros((mbh * 2, mbw * 2), np.int8)
+    """the record's MVs (x264 block order per macroblock) as the frame's 4x4 motion field + its (all zero) reference field"""
+    mv = np.asarray(mbs_mv, np.int16).reshape(mbh, mbw, 16, 2)
+    mvf = np.zeros((mbh, 4, mbw, 4, 2), np.int16)
+    for i in range(16):
+        mvf[:, BY[i], :, BX[i]] = mv[:, :, i]
+    return mvf.reshape(mbh * 4, mbw * 4, 2), np.zeros((mbh * 2, mbw * 2), np.int8)
 
 
 def carrier_lsbs(mbs):

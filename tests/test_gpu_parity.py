@@ -128,6 +128,95 @@ def test_block_costs_match_oracle(pc):
     enc.close(); o.close()
 
 
+def _probe_req(a, b, top=None, left=None, avail=3):
+    """one request of pcamv_gpu_rd_probe: a / b = (Y 16x16, U 8x8, V 8x8); top [3][28], left [3][16]"""
+    r = np.zeros(1024, np.uint8)
+    for k, blk in enumerate((a, b)):
+        m = np.zeros((24, 16), np.uint8)
+        m[:16] = blk[0]; m[16:, :8] = blk[1]; m[16:, 8:] = blk[2]
+        r[384 * k:384 * (k + 1)] = m.ravel()
+    if top is not None:
+        r[768:852] = np.asarray(top, np.uint8).ravel()
+        r[852:900] = np.asarray(left, np.uint8).ravel()
+    r[900:904] = np.frombuffer(np.int32(avail).tobytes(), np.uint8)
+    return r
+
+
+def test_rd_metrics_and_intra_predictors_match_reference_vectors(pc):
+    """SURVEY a3 and the intra predictors, probed directly (pcamv_gpu_rd_probe): ssd 16x16 / 8x8, hadamard_ac 16x16 against the
+    vectors the reference's own pixel.c produced (tests/golden/primitives_rd.npz hac_res), the psy-RD energies and ssd_mb's psy
+    term against the oracle's sa8d / satd / hadamard_ac (pinned on the same file), every 16x16 / chroma / 4x4 predictor of
+    common/predict.c through its SATD (and, at subme 1, SAD) against the pixels the reference's predictors wrote (ipred_out)."""
+    import ctypes as C
+    import orc
+    g = helpers.load("primitives_rd")
+    L = orc.lib()
+    L.orc_hadamard_ac.restype = C.c_uint64
+    rng = np.random.default_rng(9)
+    qp = 26
+    enc = pc.Encoder(_params(pc, 176, 144, 1, 6, 0x10, 64))          # subme 6: SATD, psy-RD 1.0
+    enc1 = pc.Encoder(_params(pc, 176, 144, 1, 1, 0x10, 64))         # subme 1: the intra costs are SADs
+    lam = [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91][qp]
+
+    def ptr(a):
+        return C.c_void_p(a.ctypes.data)
+
+    # ---- ssd / hadamard_ac / psy energies
+    reqs, exp = [], []
+    for i in range(len(g["hac_pix"])):
+        by = np.ascontiguousarray(g["hac_pix"][i][:, :16])                       # the block whose hadamard_ac the reference computed
+        ay = np.ascontiguousarray(g["hac_other"][i])
+        au, av, bu, bv = [rng.integers(0, 256, (8, 8), dtype=np.uint8) for _ in range(4)]
+        if i % 3 == 0:
+            bu, bv = au.copy(), av.copy()
+        reqs.append(_probe_req((ay, au, av), (by, bu, bv)))
+        ssd = L.orc_ssd(0, ptr(ay), 16, ptr(by), 16) + L.orc_ssd(3, ptr(au), 8, ptr(bu), 8) + L.orc_ssd(3, ptr(av), 8, ptr(bv), 8)
+        assert ssd == int(((ay.astype(int) - by) ** 2).sum() + ((au.astype(int) - bu) ** 2).sum() + ((av.astype(int) - bv) ** 2).sum())
+        zero = np.zeros((16, 16), np.uint8)
+        satd_sum = sum(L.orc_satd(6, ptr(zero), 16, C.c_void_p(ay.ctypes.data + 4 * y * 16 + 4 * x), 16) -
+                       (L.orc_sad(6, ptr(zero), 16, C.c_void_p(ay.ctypes.data + 4 * y * 16 + 4 * x), 16) >> 1) for y in range(4) for x in range(4))
+        sa8d_sum = sum(L.orc_sa8d(3, ptr(zero), 16, C.c_void_p(ay.ctypes.data + 8 * y * 16 + 8 * x), 16) -
+                       (L.orc_sad(3, ptr(zero), 16, C.c_void_p(ay.ctypes.data + 8 * y * 16 + 8 * x), 16) >> 2) for y in range(2) for x in range(2))
+        h4, h8 = int(g["hac_res"][i, 0, 0]), int(g["hac_res"][i, 0, 1])        # reference-minted
+        acs = L.orc_hadamard_ac(0, ptr(by), 16)
+        assert (acs & 0xffffffff, acs >> 32) == (h4, h8)
+        psy = (abs(h4 - satd_sum) + abs(h8 - sa8d_sum)) >> 1
+        exp.append((ssd, ssd + ((psy * 256 * lam + 128) >> 8), h4, h8, satd_sum, sa8d_sum))
+    got = enc.rd_probe(qp, np.stack(reqs))
+    for i, e in enumerate(exp):
+        assert tuple(int(v) for v in got[i, :6]) == e, (i, got[i, :6].tolist(), e)
+
+    # ---- intra predictors: mode m of kind k on the borders of ipred_in, scored against a random source block
+    need = {0: {0: 3, 1: 3, 2: 3, 3: 3, 4: 1, 5: 2, 6: 0}, 1: {0: 3, 1: 3, 2: 3, 3: 3, 4: 1, 5: 2, 6: 0}}
+    slot = {0: {0: 6, 1: 7, 2: 8, 3: 9, 4: 8, 5: 8, 6: 8}, 1: {0: 10, 1: 11, 2: 12, 3: 13, 4: 10, 5: 10, 6: 10}}
+    reqs, chk = [], []
+    for buf, outp, (kind, mode) in zip(g["ipred_in"], g["ipred_out"], g["ipred_kind"]):
+        kind, mode = int(kind), int(mode)
+        fy = rng.integers(0, 256, (16, 16), dtype=np.uint8); fu = rng.integers(0, 256, (8, 8), dtype=np.uint8); fv = rng.integers(0, 256, (8, 8), dtype=np.uint8)
+        top = np.zeros((3, 28), np.uint8); left = np.zeros((3, 16), np.uint8)
+        n = (16, 8, 4)[kind]
+        planes = (0,) if kind != 1 else (1, 2)
+        for c in planes:
+            top[c, 3] = buf[7, 7]; top[c, 4:4 + (24 if kind == 0 else 8)] = buf[7, 8:8 + (24 if kind == 0 else 8)]
+            left[c, :n] = buf[8:8 + n, 7]
+        pred = np.ascontiguousarray(outp[8:8 + n, 8:8 + n])
+        avail = need[kind][mode] if kind < 2 else 3
+        reqs.append(_probe_req((fy, fu, fv), (fy, fu, fv), top, left, avail))
+        chk.append((kind, mode, fy, fu, fv, pred))
+    for e, fn in ((enc, L.orc_satd), (enc1, L.orc_sad)):
+        got = e.rd_probe(qp, np.stack(reqs))
+        for i, (kind, mode, fy, fu, fv, pred) in enumerate(chk):
+            if kind == 0:
+                want, have = fn(0, ptr(fy), 16, ptr(pred), 16), int(got[i, slot[0][mode]])
+            elif kind == 1:
+                want, have = fn(3, ptr(fu), 8, ptr(pred), 8) + fn(3, ptr(fv), 8, ptr(pred), 8), int(got[i, slot[1][mode]])
+            else:
+                blk = np.ascontiguousarray(fy[:4, :4])
+                want, have = fn(6, ptr(blk), 4, ptr(pred), 4), int(got[i, 14 + mode])
+            assert want == have, (("satd", "sad")[fn is L.orc_sad], kind, mode, i, want, have)
+    enc.close(); enc1.close()
+
+
 RD_SWEEP = [
     # (W, H, me, subme, qp, seed, static_cols, cabac, psy_rd, noise, embed)
     (176, 144, "hex", 6, 12, 51, 32, 1, 1.0, 40, 1),       # low QP: long level prefixes / escapes
@@ -503,7 +592,7 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     enc.close(); o.close(); o2.close()
 
 
-def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate=0.5, statics=(0, 64, 128), noise=6):
+def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate=0.5, statics=(0, 64, 128), noise=6, hashes=False):
     """GOPs advanced together through closed-loop steps (dataflow analysis, embedding, then pass 2 + loop filter through the same
     dataflow queue; every later step's reference is the step's own deblocked picture and final motion field, both taken from the
     device): records, embedding vectors, deblocked pictures vs the oracle, and the payload back out of the final motion vectors
@@ -523,6 +612,10 @@ def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate
     batch = pc.Batch(encs)
     batch.set_closed_loop(True)
     oracles = [orc.Oracle(op) for _ in range(n_gops)]
+    ohash = [o.debug_state_hash() for o in oracles] if hashes else None      # (CABAC: the 460 context states after every macroblock)
+    if hashes:
+        for enc in encs:
+            enc.debug_state_hash(True)
     lcgs = [pc.StcLcg(1) for _ in range(n_gops)]
     refs = [clips[g][0] for g in range(n_gops)]
     prevs = [(None, None)] * n_gops
@@ -541,6 +634,9 @@ def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate
             mbs, emb = enc.fetch_results(want_embed=True)
             o.set_ref(*refs[g], *prevs[g]); o.set_fenc(*clips[g][t])
             mbs_o, _ = o.analyse_pframe(qp, 1)
+            if hashes:
+                bad = np.nonzero(enc.state_hash_fetch() != ohash[g])[0]
+                assert len(bad) == 0, f"step {t} GOP {g}: CABAC context states differ from macroblock {bad[0]} on ({len(bad)} in all)"
             for f in mbs.dtype.names:
                 assert np.array_equal(mbs[f], mbs_o[f]), f"step {t} GOP {g}: {f}"
             emb_o = o.embed_pframe(mbs_o, emrate)
@@ -602,6 +698,80 @@ def test_rd_instances_agree(pc, monkeypatch):
     assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 3, 2, 71) > 0
     test_rd_mode_decision_matches_oracle(pc, RD_SWEEP[1])
     test_rd_mode_decision_matches_oracle(pc, RD_SWEEP[6])
+
+
+FINAL_SLICES = ["pslice_qcif_hex_subme5_final", "pslice_cif_umh_subme7_final", "pslice_cavlc_cif_umh_subme7_final"]
+
+
+@pytest.mark.parametrize("name", FINAL_SLICES)
+def test_final_mvs_are_what_a_decoder_reads(pc, name):
+    """SURVEY 8f rank 1 chained to the GPU: pass 1 + embedding + pass 2 on the GPU from the fixture's pictures; the slice the
+    REFERENCE's entropy coder wrote for the same frame (its own second pass with the same flips) is parsed by the MV-syntax
+    extractor: types, partitions and final motion vectors agree, and the payload the GPU embedded comes back out of the parsed
+    stream's motion (decode-side BER = 0 on GPU output)."""
+    g = helpers.load(name)
+    W, H, qp = int(g["width"]), int(g["height"]), int(g["qp"])
+    cabac = int(g["cabac"])
+    p = _params(pc, W, H, int(g["me"]), int(g["subme"]), int(g["inter"]) & 0x30, int(g["mv_range"]), cabac=cabac)
+    enc = pc.Encoder(p)
+    enc.set_ref(g["ref_y"], g["ref_u"], g["ref_v"]); enc.upload_fenc(g["fenc_y"], g["fenc_u"], g["fenc_v"])
+    mbs, _ = enc.analyse_pframe(qp, embed=1)
+    emb = enc.embed_pframe(0.5)
+    fin, _, _ = enc.pass2_pframe()
+    rbsp, _, _ = pc.nal_to_rbsp(g["nal"].tobytes())
+    got = pc.parse_pslice_at(rbsp, int(g["nal_hdr_bits"]), W // 16, H // 16, qp if cabac else None)
+    assert np.array_equal(got["i_type"], mbs["i_type"]) and np.array_equal(got["i_partition"], mbs["i_partition"])
+    bad = np.argwhere((got["mv"] != fin["mv"]).reshape(len(fin), -1).any(1)).ravel()
+    assert len(bad) == 0, f"final motion differs from the stream's at macroblocks {bad[:8].tolist()}"
+    got["used"] = mbs["used"]
+    lsb = helpers.carrier_lsbs(got)
+    assert len(lsb) == emb["n"] == int(g["n"]) and np.array_equal(lsb, emb["stego"])
+    msg = pc.stc_extract(lsb, emb["m"])
+    assert np.array_equal(msg, emb["message"]) and np.array_equal(msg, g["message"]), "decode-side BER != 0"
+    enc.close()
+
+
+def test_mvsyntax_extractor_rows_on_the_gpu_box(pc):
+    """the extractor's own suite (host code of the same library; tests/test_mvsyntax.py, CPU suite) once more where the GPU tests
+    run, so that the row is covered by the run that records which native code was loaded"""
+    import test_mvsyntax as tm
+    for name in tm.FIXTURES:
+        tm.test_parser_reads_back_what_the_reference_coded(name)
+        tm.test_slice_data_inside_a_nal_unit_behind_a_header(name)
+        if name.endswith("_final"):
+            tm.test_payload_comes_back_out_of_the_stream(name)
+    tm.test_damaged_streams_are_reported()
+    tm.test_skip_run_beyond_the_picture_is_reported()
+
+
+def test_batch_survives_a_closed_context(pc):
+    """a context closed before its batch: every batch entry point reports it (PCAMV_EINVAL), none dereferences the dead slot"""
+    import ctypes as C
+    W, H = 176, 144
+    encs = [pc.Encoder(_params(pc, W, H, 1, 5, 0x10, 64)) for _ in range(3)]
+    batch = pc.Batch(encs)
+    encs[1].close()
+    assert batch.dominant_kernel() == "k_analyse_flow"
+    batch.kernel_time(reset=True)
+    with pytest.raises(pc.PcamvError, match="closed"):
+        batch.step(26, 0.5, 0)
+    buf = np.zeros(3 * 99 * 236, np.uint8)
+    with pytest.raises(pc.PcamvError, match="closed"):
+        batch.copy_results_async(buf.ctypes.data, 99 * 236)
+    batch.close()
+    encs[0].close(); encs[2].close()
+
+
+def test_bench_regime_matches_oracle(pc, monkeypatch):
+    """The regime bench.py times, against the oracle: --me umh --subme 7 with CABAC (analyse.c:2117-2186, rdo.c:139-171), the
+    4-waves-per-SIMD build of the RD kernel, eight per-XCD queues (40 closed GOPs = five chains per queue), fewer waves than chains
+    (12: a wave that finishes a macroblock takes whatever chain's next one is ready, queues without a wave of their own are drained
+    by work stealing), the second pass in tasks of 8 macroblocks; three closed-loop steps; of EVERY GOP the records, the context states
+    after every macroblock, the embedding vectors, the deblocked planes and the payload back out of the final motion vectors."""
+    monkeypatch.setenv("PCAMV_RD_INSTANCE", "hi")
+    monkeypatch.setenv("PCAMV_PASS2_UNIT", "8")
+    monkeypatch.setenv("PCAMV_FLOW_WAVES", "12")
+    assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 40, 3, 171, hashes=True) > 0
 
 
 @pytest.mark.parametrize("unit", [3, 8])

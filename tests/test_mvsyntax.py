@@ -53,6 +53,40 @@ def test_payload_comes_back_out_of_the_stream(name):
     assert np.array_equal(msg, g["message"]), "decode-side BER != 0"
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_slice_data_inside_a_nal_unit_behind_a_header(name):
+    """the NAL layer and an unaligned slice header in front: the NAL unit was escaped by the reference's own x264_nal_encode
+    (common/common.c:658; 00 00 03 inserted in the zero-filled stand-in header of the CABAC fixtures, and 6 times inside the
+    QP-10 CAVLC slice), the slice data starts at bit nal_hdr_bits of the RBSP (CABAC: after the alignment ones)"""
+    import pcamv_amd
+    g = helpers.load(name)
+    nal = g["nal"].tobytes()
+    assert nal[:4] == b"\x00\x00\x00\x01"
+    rbsp, ref_idc, typ = pcamv_amd.nal_to_rbsp(nal)
+    assert (ref_idc, typ) == (2, 1) and len(nal) - 5 - len(rbsp) == int(g["nal_escapes"])
+    assert pcamv_amd.nal_to_rbsp(nal[4:])[0] == rbsp and pcamv_amd.nal_to_rbsp(nal[1:])[0] == rbsp       # no / short start code
+    cabac = not ("cabac" in g and not int(g["cabac"]))
+    got = pcamv_amd.parse_pslice_at(rbsp, int(g["nal_hdr_bits"]), int(g["width"]) // 16, int(g["height"]) // 16, int(g["qp"]) if cabac else None)
+    for a, b in (("type", "i_type"), ("partition", "i_partition"), ("sub_partition", "i_sub_partition"), ("mv", "mv")):
+        assert np.array_equal(g[a], got[b]), a
+    with pytest.raises(pcamv_amd.PcamvError):           # one bit off: an error, never a crash (CABAC: the alignment bits are checked)
+        off = pcamv_amd.parse_pslice_at(rbsp, int(g["nal_hdr_bits"]) - (3 if cabac else 1), int(g["width"]) // 16, int(g["height"]) // 16, int(g["qp"]) if cabac else None)
+        if np.array_equal(off["mv"], g["mv"]):
+            raise AssertionError("a shifted start parsed to the same motion")
+        raise pcamv_amd.PcamvError("different motion")
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.nal_to_rbsp(b"\x00\x00\x01\x41\x12\x00\x00\x01\x33")      # a start code inside the unit
+
+
+def test_skip_run_beyond_the_picture_is_reported():
+    """CAVLC: an mb_skip_run that claims more macroblocks than the picture has left (ue(12) = 0001101, then the trailing bit)"""
+    import pcamv_amd
+    with pytest.raises(pcamv_amd.PcamvError):
+        pcamv_amd.parse_pslice_cavlc(bytes([0b00011011, 0b00000000]), 3, 3)
+    got = pcamv_amd.parse_pslice_cavlc(bytes([0b00010101]), 3, 3)             # ue(9) = 0001010 + trailing 1: nine skipped macroblocks
+    assert (got["i_type"] == pcamv_amd.P_SKIP).all()
+
+
 def test_damaged_streams_are_reported():
     import pcamv_amd
     g = helpers.load("pslice_qcif_hex_subme5_final")

@@ -34,6 +34,7 @@ struct pcamv_batch {
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
     int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo;
+    int b_mbrd, b_tesa;         /* instance of the analysis kernel the batch's contexts need (fixed at creation) */
     unsigned *d_flow;
     FlowDev fl, fl2;          /* queue descriptors of the analysis and of the second pass */
     char err[256];
@@ -152,6 +153,8 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     if (!b) return PCAMV_ENOMEM;
     memset((void *)b, 0, sizeof(*b));
     b->n = n; b->device = ctxs[0]->device; b->W = ctxs[0]->F.w; b->H = ctxs[0]->F.h;
+    b->b_mbrd = ctxs[0]->F.b_mbrd;
+    for (int i = 0; i < n; i++) b->b_tesa |= ctxs[i]->F.me_method == PCAMV_ME_TESA;
     b->ctx = (pcamv_ctx **)malloc(sizeof(pcamv_ctx *) * n);
     for (int i = 0; i < n; i++) b->ctx[i] = ctxs[i];
     const FrameDev &F = ctxs[0]->F;
@@ -249,8 +252,8 @@ extern "C" int pcamv_gpu_recon_device(pcamv_ctx_t *c, void *planes[3])
 static const char *dominant_kernel(const pcamv_batch *b)
 {
     if (!b || !b->sched_flow) return "k_search_diag";
-    if (b->n > 0 && b->ctx[0]->F.b_mbrd) return "k_analyse_flow_rd";
-    for (int i = 0; i < b->n; i++) if (b->ctx[i]->F.me_method == PCAMV_ME_TESA) return "k_analyse_flow_tesa";
+    if (b->b_mbrd) return "k_analyse_flow_rd";       /* (what batch_create saw: contexts may have been closed since, their slots are NULL) */
+    if (b->b_tesa) return "k_analyse_flow_tesa";
     return "k_analyse_flow";
 }
 extern "C" const char *pcamv_gpu_batch_dominant_kernel(const pcamv_batch_t *b) { return dominant_kernel(b); }
@@ -259,6 +262,7 @@ extern "C" int pcamv_gpu_batch_copy_results_async(pcamv_batch_t *b, void *dst_mb
     if (!b || !dst_mb) return PCAMV_EINVAL;
     HIPCHKB(b, hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < b->n; i++) if (!b->ctx[i]) return bfail(b, PCAMV_EINVAL, "context %d of the batch was closed", i);
     for (int i = 0; i < b->n; i++) {
         pcamv_ctx *c = b->ctx[i];
         const size_t nb = (size_t)c->F.n_mb * sizeof(pcamv_mb_t);
@@ -849,6 +853,28 @@ extern "C" int pcamv_gpu_block_costs(pcamv_ctx_t *c, int qp, int n, const int32_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, d_out, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost));
     hipFree(d_req); hipFree(d_out); hipFree(d_F);
+    return 0;
+}
+
+extern "C" int pcamv_gpu_rd_probe(pcamv_ctx_t *c, int qp, int n, const uint8_t *req, int32_t *out)
+{
+    if (!c || !req || !out || n <= 0) return PCAMV_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_qp(c, qp);
+    if (rc) return rc;
+    uint8_t *d_req = NULL; int *d_out = NULL; FrameDev *d_F = NULL;
+    hipError_t e = dalloc(&d_req, (size_t)n * 1024);
+    if (e == hipSuccess) e = dalloc(&d_out, (size_t)n * 32);
+    if (e == hipSuccess) e = dalloc(&d_F, 1);
+    if (e == hipSuccess) e = hipMemcpy(d_req, req, (size_t)n * 1024, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_F, &c->F, sizeof(FrameDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rd_probe, dim3(n), dim3(64), 0, c->stream, (const FrameDev *)d_F, (const uint8_t *)d_req, d_out);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 32 * sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d_req); hipFree(d_out); hipFree(d_F);
+    if (e != hipSuccess) return fail(c, PCAMV_EHIP, "rd_probe: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -18,11 +18,19 @@
 #include "pcamv_mbkernels.h"
 #include "stc_mats.h"
 
+/* The kernels every instance of the library shares (plane production, the second pass, the embedding stage, the common analysis
+ * kernel, the probes) are compiled by ONE translation unit, pcamv_gpu.hip; the units of the --me tesa and RD instances take only the
+ * templates and types from this header (round 2 compiled -- and shipped -- every kernel four times). */
+#if !defined(PCAMV_TESA_TU) && !defined(PCAMV_RD_TU)
+#define PCAMV_MAIN_TU 1
+#endif
+
 /* ------------------------------------------------------------------ plane production */
 /* Every kernel is batched over independent closed GOPs: blockIdx.z (plane kernels) or blockIdx.y
  * (macroblock kernels) selects the GOP's FrameDev in a device array.  One launch then carries
  * the same dependency step of all GOPs, which is what fills the 256 CUs (a single 1080p frame
  * exposes at most 60 independent macroblocks at a time). */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__restrict__ Fs)
 {
     const FrameDev &F = Fs[blockIdx.z >> 1];
@@ -41,6 +49,7 @@ static __global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__res
     else v = rowp[gx] | rowp[gx + 1] << 8 | rowp[gx + 2] << 16 | (uint32_t)rowp[gx + 3] << 24;
     *(uint32_t *)(dst + (size_t)y * cstride + x) = v;
 }
+#endif
 
 /* clamp to [0,255] of an already shifted value.  The empty asm keeps hipcc (ROCm 7.2) from fusing
  * shift + clamp of two neighbours into v_ashr_pk_u8_i32: the code it emits around that gfx950
@@ -75,6 +84,7 @@ __device__ __forceinline__ void hpel_load_row(const uint8_t *__restrict__ rowp, 
         }
     }
 }
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__restrict__ Fs)
 {
     const FrameDev &F = Fs[blockIdx.z];
@@ -148,6 +158,7 @@ static __global__ void __launch_bounds__(HP_THREADS) k_hpel(const FrameDev *__re
         }
     }
 }
+#endif
 
 /* ------------------------------------------------------------------ analysis phases */
 template <int TESA>
@@ -162,6 +173,7 @@ __global__ void __launch_bounds__(64) k_search_diag(const FrameDev *__restrict__
     if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
     mbk_search<TESA>(F, &L, &A, x, y);
 }
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ Fs, int slots_per_mb)
 {
     __shared__ MBLocal L;
@@ -172,6 +184,8 @@ static __global__ void __launch_bounds__(64) k_rca(const FrameDev *__restrict__ 
     if (xy >= F.n_mb) return;
     mbk_rca(F, &L, &A, xy, k);
 }
+#endif
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict__ Fs)
 {
     __shared__ MBLocal L;
@@ -180,8 +194,10 @@ static __global__ void __launch_bounds__(64) k_encode(const FrameDev *__restrict
     if ((int)blockIdx.x >= F.n_mb) return;
     mbk_encode(F, &L, &A, blockIdx.x);
 }
+#endif
 
 /* ------------------------------------------------------------------ pass 2 + loop filter */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_pass2_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
@@ -191,6 +207,7 @@ static __global__ void __launch_bounds__(64) k_pass2_diag(const FrameDev *__rest
     if (y >= F.mb_h || x < 0 || x >= F.mb_w) return;
     mbk_pass2(F, &L, x, y);
 }
+#endif
 
 /* H.264 Tables 8-16 / 8-17: alpha(indexA), beta(indexB), tc0(indexA, bS = 1..3) */
 __device__ static const uint8_t dbk_alpha_dev[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28,
@@ -336,6 +353,7 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
       NB_ST32(dst + (size_t)(cgy - 4 + r) * CW + cgx + c, *(const uint32_t *)&sc[pl][r][c + 4]); }
 }
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ DeblockLDS D;
@@ -345,9 +363,11 @@ static __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__re
     if (my >= F.mb_h || mx < 0 || mx >= F.mb_w) return;
     mbk_deblock(F, &D, mx, my);
 }
+#endif
 
 /* both stages of one anti-diagonal in one launch: the filter of (x,y) only needs the pass-2 reconstruction of
  * (x,y) itself and the filtered neighbours of earlier diagonals, and only modifies macroblocks of earlier diagonals */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
     __shared__ MBLocal L;
@@ -361,6 +381,7 @@ static __global__ void __launch_bounds__(64) k_pass2_deblock_diag(const FrameDev
     __syncthreads();
     mbk_deblock(F, &D, x, y);
 }
+#endif
 
 /* ------------------------------------------------------------------ dataflow scheduling of the analysis
  * One persistent launch per frame step instead of one launch per anti-diagonal: macroblock (x,y) of a
@@ -393,6 +414,7 @@ struct FlowDev {
 #define FLOW_ERR 512
 #define FLOW_CTR_WORDS 576
 
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
 {
     unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -407,6 +429,7 @@ static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
     fl.queue[i] = k < ngop_q ? ((k * (unsigned)fl.nq + (unsigned)q) << 16) + 1u : 0u;
     if (i < 8) { fl.ctr[FLOW_HEAD(i)] = 0u; fl.ctr[FLOW_TAIL(i)] = fl.qcount[i] / (unsigned)fl.n_mb; }     /* heads 0, tails = GOPs of the queue; the error flag is the host's */
 }
+#endif
 
 __device__ __forceinline__ unsigned flow_bcast(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot, unsigned item)
@@ -527,12 +550,14 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
     PROF_FLUSH();
 }
 
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_analyse_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
     flow_loop<0, 0>(Fs, fl, L, &A, nullptr);
 }
+#endif
 /* The same kernel with --me tesa compiled in (pcamv_logic.h: the search functions are templates on it) lives in a
  * translation unit of its own, csrc/pcamv_tesa.hip, built in parallel with this one; the library calls it through
  * this launcher. */
@@ -567,15 +592,18 @@ int pcamv_flow_rd_waves_per_cu_lo(void);
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the
  * filter reads its neighbourhood with agent-scope loads (NB_LD*).  (With an agent-scope release + acquire per
  * macroblock this was slower than one launch per anti-diagonal: 245 vs 176 ms per closed-loop step at G=256.) */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ DeblockLDS D;
     flow_loop<1, 0>(Fs, fl, L, nullptr, &D);
 }
+#endif
 
 /* block-cost probe: the pixel metrics of a1/a2/a5/a6 (SAD, SATD, qpel fetch, chroma MC) at arbitrary
  * positions, for checkasm-style parity tests through the C ABI.  req = {mb_x,mb_y,ip,xoff,yoff,mx,my,satd} */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__restrict__ Fs, const int *__restrict__ req, int *__restrict__ out)
 {
     __shared__ MBLocal L;
@@ -598,6 +626,51 @@ static __global__ void __launch_bounds__(64) k_block_costs(const FrameDev *__res
     prim_eval_list(F, &L, L.fenc, r[2], r[3], r[4], 1, mflag | EV_CHROMA | EV_PROBE, 0, 0);
     if (LANE() == 0) { out[3 * blockIdx.x] = L.ccost[0]; out[3 * blockIdx.x + 1] = L.ccost[64]; out[3 * blockIdx.x + 2] = L.ccost[128]; }
 }
+#endif
+
+/* probe of the RD stage's pixel metrics and intra predictors (SURVEY a3 + the intra SATD analysis of --subme >= 6) on caller-supplied
+ * pixels, for parity tests against reference-minted vectors through the C ABI.  One request = 1024 bytes: source macroblock
+ * (fenc layout: Y 16x16, then U | V 8x8 side by side, stride 16), a second macroblock in the same layout ("reconstruction"),
+ * intra borders top[3][28] ([c][3] = top left, [c][4 + x]) and left[3][16], int32 avail (bit 0 left, bit 1 top) at byte 900.
+ * out[32]: 0 ssd of the macroblock without the psy term (x264_pixel_ssd 16x16 + 2 x 8x8, pixel.c:71-96), 1 the same with it
+ * (ssd_mb, rdo.c:106-137), 2 / 3 hadamard_ac 16x16 of the second block (pixel.c:306-358; 4x4 / 8x8 energies), 4 / 5 the source's
+ * psy-RD energies (x264_mb_cache_fenc_satd, analyse.c:522-549: satd / sa8d sums), 6..9 intra 16x16 costs V, H, DC (the variant avail
+ * allows), P (common/predict.c + satd or, at subme 1, sad), 10..13 intra chroma DC, H, V, P over both planes, 14..25 the twelve 4x4
+ * modes of block 0 (I4_V .. I4_DC_128); an unavailable mode answers PCAMV_COST_MAX */
+#ifdef PCAMV_MAIN_TU
+static __global__ void __launch_bounds__(64) k_rd_probe(const FrameDev *__restrict__ Fs, const uint8_t *__restrict__ req, int *__restrict__ out)
+{
+    __shared__ MBLocal L;
+    const FrameDev F = Fs[0];
+    const int lane = LANE();
+    const uint8_t *r = req + 1024 * (size_t)blockIdx.x;
+    int *o = out + 32 * blockIdx.x;
+    for (int i = lane; i < 96; i += 64) { ((uint32_t *)L.fenc)[i] = ((const uint32_t *)r)[i]; ((uint32_t *)L.pred)[i] = ((const uint32_t *)(r + 384))[i]; }
+    for (int i = lane; i < 84; i += 64) ((uint8_t *)L.ib_top)[i] = r[768 + i];
+    if (lane < 48) ((uint8_t *)L.ib_left)[lane] = r[852 + lane];
+    const int avail = *(const int *)(r + 900);
+    if (lane == 0) { L.mb_x = L.mb_y = L.mb_xy = 0; L.neighbour = (avail & 1 ? NB_LEFT : 0) | (avail & 2 ? NB_TOP | NB_TOPRIGHT : 0) | (avail == 3 ? NB_TOPLEFT : 0); }
+    PCAMV_WAVE_SYNC();
+    FrameDev F0 = F;
+    F0.psy_rd = 0;
+    const int ssd0 = prim_ssd_mb(F0, &L);
+    prim_fenc_complexity(F, &L);
+    const int ssd1 = prim_ssd_mb(F, &L);
+    int h4, h8;
+    prim_hadamard_ac16(L.pred, lane, &h4, &h8);
+    if (lane == 0) { o[0] = ssd0; o[1] = ssd1; o[2] = h4; o[3] = h8; o[4] = L.fenc_satd_sum; o[5] = L.fenc_sa8d_sum; }
+    prim_intra16_satd(F, &L, avail);
+    if (lane < 4) o[6 + lane] = L.ccost[lane];
+    PCAMV_WAVE_SYNC();
+    prim_intra8c_satd(F, &L, avail);
+    if (lane < 4) o[10 + lane] = L.ccost[lane];
+    PCAMV_WAVE_SYNC();
+    prim_intra4_init(&L);
+    if (lane < 12) L.slots[lane] = lane;
+    prim_intra4_costs(F, &L, 0, 12, 0);
+    if (lane < 12) o[14 + lane] = L.ccost[lane];       /* (every mode is computed on the borders as given: availability is the caller's business) */
+}
+#endif
 
 /* ------------------------------------------------------------------ embedding stage */
 #define STC_MAXW 256
@@ -653,6 +726,7 @@ __device__ int dev_stc_matrix(int width, int height, unsigned *cols, long long *
     return 1;
 }
 
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *__restrict__ Es)
 {
     const EmbedDev E = Es[blockIdx.x];
@@ -802,6 +876,7 @@ static __global__ void __launch_bounds__(1024) k_embed_prepare(const EmbedDev *_
         if (l == 0) *(double *)(E.hdr + 6) = total;
     }
 }
+#endif
 
 /* forward Viterbi over the 1024 trellis states: new[s] = min(p[s] + c_stay, p[s^col] + c_flip), path bit set
  * when the flip branch is <= (embed.h:439-467 evaluated per state; ties and infinities behave identically
@@ -885,6 +960,7 @@ __global__ void __launch_bounds__(1024 / NS) k_stc_forward(const EmbedDev *__res
  * word w of every row in lane w, so the serial walk is scalar code around one v_readlane per column; the
  * column's constants (colinfo) come from the lane of the same number.  The walk's state is wave-uniform: the
  * compiler keeps it in SGPRs. */
+#ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__restrict__ Es)
 {
     const EmbedDev E = Es[blockIdx.x];
@@ -923,4 +999,5 @@ static __global__ void __launch_bounds__(64) k_stc_backward(const EmbedDev *__re
     nf = wave_sum_all(nf);
     if (lane == 0) { E.hdr[3] = nf; E.hdr[2] = E.hdr[2] == -2 ? 1 : 0; }
 }
+#endif
 #endif

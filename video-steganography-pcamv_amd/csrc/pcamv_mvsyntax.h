@@ -490,6 +490,7 @@ struct ParserV {
                 ftype[xy] = (int8_t)o->i_type;
                 if (b.overrun) return PCAMV_EINVAL;
             }
+        if (skip_run > 0) return PCAMV_EINVAL;       /* the last mb_skip_run claims more macroblocks than the picture has left */
         /* rbsp_slice_trailing_bits: a 1 and zeros up to the byte boundary, within the last byte(s) handed over */
         if (b.pos >= b.nbits || !b.get(1)) return PCAMV_EINVAL;
         while (b.pos < b.nbits) if (b.get(1)) return PCAMV_EINVAL;
@@ -514,7 +515,54 @@ extern "C" int pcamv_gpu_parse_pslice_cabac(const uint8_t *data, size_t len, int
     free(P.fmv); free(P.fmvd); free(P.fnz); free(P.fcbp); free(P.ftype);
     return rc;
 }
+/* The slice data where a real stream has it: inside a NAL unit (emulation prevention bytes, x264_nal_encode common/common.c:658-690)
+ * and behind a slice header of any bit length.  pcamv_gpu_nal_to_rbsp undoes the NAL layer; the _at forms start at a bit of the
+ * RBSP: CAVLC slice data follows the header directly, CABAC slice data after cabac_alignment_one_bits up to the byte boundary. */
+extern "C" int pcamv_gpu_nal_to_rbsp(const uint8_t *nal, size_t len, uint8_t *rbsp, size_t *rbsp_len, int *nal_ref_idc, int *nal_unit_type)
+{
+    if (!nal || !rbsp || !rbsp_len) return PCAMV_EINVAL;
+    size_t i = 0;
+    if (len >= 4 && nal[0] == 0 && nal[1] == 0 && nal[2] == 0 && nal[3] == 1) i = 4;           /* Annex B start code, long or short */
+    else if (len >= 3 && nal[0] == 0 && nal[1] == 0 && nal[2] == 1) i = 3;
+    if (i >= len || (nal[i] & 0x80)) return PCAMV_EINVAL;                                       /* forbidden_zero_bit */
+    if (nal_ref_idc) *nal_ref_idc = (nal[i] >> 5) & 3;
+    if (nal_unit_type) *nal_unit_type = nal[i] & 31;
+    i++;
+    size_t n = 0; int zeros = 0;
+    for (; i < len; i++) {
+        if (zeros >= 2 && nal[i] == 3) {            /* emulation_prevention_three_byte: dropped */
+            if (i + 1 < len && nal[i + 1] > 3) return PCAMV_EINVAL;     /* 00 00 03 xx with xx > 03 does not occur in a NAL unit */
+            zeros = 0;
+            continue;
+        }
+        if (zeros >= 2 && nal[i] < 3) return PCAMV_EINVAL;              /* 00 00 00 / 01 / 02 inside a NAL unit: the next start code, not payload */
+        zeros = nal[i] == 0 ? zeros + 1 : 0;
+        rbsp[n++] = nal[i];
+    }
+    *rbsp_len = n;
+    return 0;
+}
+extern "C" int pcamv_gpu_parse_pslice_cabac(const uint8_t *data, size_t len, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb);
+extern "C" int pcamv_gpu_parse_pslice_cabac_at(const uint8_t *rbsp, size_t len, size_t start_bit, int mb_w, int mb_h, int slice_qp, pcamv_mb_t *out_mb)
+{
+    if (!rbsp || start_bit > len * 8) return PCAMV_EINVAL;
+    while (start_bit & 7) {                         /* cabac_alignment_one_bit */
+        if (!((rbsp[start_bit >> 3] >> (7 - (start_bit & 7))) & 1)) return PCAMV_EINVAL;
+        start_bit++;
+    }
+    return pcamv_gpu_parse_pslice_cabac(rbsp + (start_bit >> 3), len - (start_bit >> 3), mb_w, mb_h, slice_qp, out_mb);
+}
+static int parse_pslice_cavlc_bits(const uint8_t *data, size_t len, size_t start_bit, int mb_w, int mb_h, pcamv_mb_t *out_mb);
+extern "C" int pcamv_gpu_parse_pslice_cavlc_at(const uint8_t *rbsp, size_t len, size_t start_bit, int mb_w, int mb_h, pcamv_mb_t *out_mb)
+{
+    if (!rbsp || start_bit >= len * 8) return PCAMV_EINVAL;
+    return parse_pslice_cavlc_bits(rbsp, len, start_bit, mb_w, mb_h, out_mb);
+}
 extern "C" int pcamv_gpu_parse_pslice_cavlc(const uint8_t *data, size_t len, int mb_w, int mb_h, pcamv_mb_t *out_mb)
+{
+    return parse_pslice_cavlc_bits(data, len, 0, mb_w, mb_h, out_mb);
+}
+static int parse_pslice_cavlc_bits(const uint8_t *data, size_t len, size_t start_bit, int mb_w, int mb_h, pcamv_mb_t *out_mb)
 {
     if (!data || !out_mb || len < 1 || mb_w < 1 || mb_h < 1) return PCAMV_EINVAL;
     const size_t n = (size_t)mb_w * mb_h;
@@ -523,7 +571,7 @@ extern "C" int pcamv_gpu_parse_pslice_cavlc(const uint8_t *data, size_t len, int
     P.fmv = (int16_t *)calloc(n * 32, sizeof(int16_t)); P.fnz = (uint8_t *)calloc(n * 24, 1); P.ftype = (int8_t *)calloc(n, 1);
     int rc = PCAMV_ENOMEM;
     if (P.fmv && P.fnz && P.ftype) {
-        P.b.d = data; P.b.nbits = len * 8; P.b.pos = 0; P.b.overrun = 0;
+        P.b.d = data; P.b.nbits = len * 8; P.b.pos = start_bit; P.b.overrun = 0;
         rc = P.run(out_mb);
     }
     free(P.fmv); free(P.fnz); free(P.ftype);

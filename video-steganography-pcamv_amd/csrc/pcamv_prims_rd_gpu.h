@@ -425,6 +425,17 @@ __device__ __forceinline__ void prim_fenc_complexity(const FrameDev &F, MBLocal 
     if (lane == 0) { L->fenc_satd_sum = satd; L->fenc_sa8d_sum = sa8d; }
     PCAMV_WAVE_SYNC();
 }
+/* x264_pixel_hadamard_ac_16x16 (common/pixel.c:306-358) of the 16x16 block in buf (stride 16): AC energy of the 4x4 transforms
+ * (low word of the reference's result) and of the 8x8 transforms (high word) */
+__device__ __forceinline__ void prim_hadamard_ac16(const uint8_t *buf, int lane, int *sum4, int *sum8)
+{
+    int s4, dc, s8;
+    had_lane_sums(buf, lane, &s4, &dc, &s8);
+    if (lane >= 16) { s4 = 0; dc = 0; s8 = 0; }
+    s4 = group_sum(s4, 16); dc = group_sum(dc, 16); s8 = group_sum(s8, 16);
+    *sum4 = (__builtin_amdgcn_readlane(s4, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 1;
+    *sum8 = (__builtin_amdgcn_readlane(s8, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 2;
+}
 /* ssd_mb (rdo.c:106-137) of the reconstruction in L->pred: SSD of luma + both chroma planes, plus for luma the psy term
  * |AC energy (4x4) difference| + |AC energy (8x8) difference| (the hadamard_ac branch: PIXEL_16x16 <= PIXEL_8x8) */
 __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
@@ -444,12 +455,8 @@ __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
     }
     int ssd = wave_sum_all(v);
     if (F.psy_rd) {
-        int s4, dc, s8;
-        had_lane_sums(L->pred, lane, &s4, &dc, &s8);
-        if (lane >= 16) { s4 = 0; dc = 0; s8 = 0; }
-        s4 = group_sum(s4, 16); dc = group_sum(dc, 16); s8 = group_sum(s8, 16);
-        const int sum4 = (__builtin_amdgcn_readlane(s4, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 1;
-        const int sum8 = (__builtin_amdgcn_readlane(s8, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 2;
+        int sum4, sum8;
+        prim_hadamard_ac16(L->pred, lane, &sum4, &sum8);
         const int satd = (iabs(sum4 - L->fenc_satd_sum) + iabs(sum8 - L->fenc_sa8d_sum)) >> 1;
         ssd += (satd * F.psy_rd * F.lambda + 128) >> 8;
     }

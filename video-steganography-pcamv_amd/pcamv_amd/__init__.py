@@ -6,7 +6,7 @@ There is no CPU fallback: importing works without a GPU, but every operation rai
 PcamvError when the library or a HIP device is missing.
 """
 from .api import (PcamvError, Params, Encoder, Batch, param_default, param_parse, level_mv_range, lib_path, build_library,
-                  MB_DTYPE, stc_extract, StcLcg, parse_pslice_cabac, parse_pslice_cavlc, load_library, ME_NAMES, P_L0, P_8x8, P_SKIP)
+                  MB_DTYPE, stc_extract, StcLcg, parse_pslice_cabac, parse_pslice_cavlc, parse_pslice_at, nal_to_rbsp, load_library, ME_NAMES, P_L0, P_8x8, P_SKIP)
 
 __all__ = ["PcamvError", "Params", "Encoder", "Batch", "param_default", "param_parse", "level_mv_range", "lib_path",
-           "build_library", "MB_DTYPE", "stc_extract", "StcLcg", "parse_pslice_cabac", "parse_pslice_cavlc", "load_library", "ME_NAMES", "P_L0", "P_8x8", "P_SKIP"]
+           "build_library", "MB_DTYPE", "stc_extract", "StcLcg", "parse_pslice_cabac", "parse_pslice_cavlc", "parse_pslice_at", "nal_to_rbsp", "load_library", "ME_NAMES", "P_L0", "P_8x8", "P_SKIP"]

@@ -57,6 +57,9 @@ def level_mv_range(width, height, fps=25):
 def _validate(p):
     """the part of x264_validate_parameters that couples these fields (encoder.c:511-522): psy-RD acts from subme 6 on and
     lowers the chroma QP offset by 2 (by 1 below strength 0.25); the user's own values are kept on the side"""
+    # (a Params() built directly, or a ctypes copy of one, has no side values: x264's defaults psy-rd 1.0 and the offset as it stands)
+    if not hasattr(p, "_f_psy_rd"):
+        p._f_psy_rd, p._chroma_qp_offset = 1.0, p.i_chroma_qp_offset
     f = p._f_psy_rd if p.i_subpel_refine >= 6 else 0.0
     p.i_psy_rd = int(min(max(f, 0.0), 10.0) * 256 + 0.5)
     off = p._chroma_qp_offset - ((1 if f < 0.25 else 2) if p.i_psy_rd else 0)
@@ -196,6 +199,35 @@ def parse_pslice_cavlc(slice_data, mb_w, mb_h):
     return mbs
 
 
+def nal_to_rbsp(nal):
+    """pcamv_gpu_nal_to_rbsp: (rbsp bytes, nal_ref_idc, nal_unit_type) of one NAL unit (Annex-B start code optional)"""
+    data = np.frombuffer(bytes(nal), np.uint8)
+    out = np.zeros(max(1, len(data)), np.uint8)
+    n, ref_idc, typ = C.c_size_t(), C.c_int(), C.c_int()
+    lib = load_library()
+    lib.pcamv_gpu_nal_to_rbsp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rc = lib.pcamv_gpu_nal_to_rbsp(_p(data), len(data), _p(out), C.byref(n), C.byref(ref_idc), C.byref(typ))
+    if rc:
+        raise PcamvError(f"pcamv_gpu_nal_to_rbsp failed: {rc}")
+    return out[:n.value].tobytes(), ref_idc.value, typ.value
+
+
+def parse_pslice_at(rbsp, start_bit, mb_w, mb_h, qp=None):
+    """pcamv_gpu_parse_pslice_cabac_at (qp given) / _cavlc_at: the slice data behind a slice header that ends at bit start_bit of the RBSP"""
+    data = np.frombuffer(bytes(rbsp), np.uint8)
+    mbs = np.zeros(mb_w * mb_h, MB_DTYPE)
+    lib = load_library()
+    if qp is None:
+        lib.pcamv_gpu_parse_pslice_cavlc_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        rc = lib.pcamv_gpu_parse_pslice_cavlc_at(_p(data), len(data), start_bit, mb_w, mb_h, _p(mbs))
+    else:
+        lib.pcamv_gpu_parse_pslice_cabac_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rc = lib.pcamv_gpu_parse_pslice_cabac_at(_p(data), len(data), start_bit, mb_w, mb_h, qp, _p(mbs))
+    if rc:
+        raise PcamvError(f"pcamv_gpu_parse_pslice_*_at failed: {rc}")
+    return mbs
+
+
 class StcLcg:
     """state of the reference's STC column generator (embed.h:134-139), carried from frame to frame by an extractor; a process --
     a closed GOP under the per-GOP parity definition -- starts at 1"""
@@ -331,6 +363,14 @@ class Encoder:
         req = np.ascontiguousarray(requests, np.int32).reshape(-1, 8)
         out = np.zeros((len(req), 3), np.int32)
         self._chk(self.lib.pcamv_gpu_block_costs(self.ctx, qp, len(req), _p(req), _p(out)), "block_costs")
+        return out
+
+    def rd_probe(self, qp, requests):
+        """pcamv_gpu_rd_probe: requests = uint8 [n, 1024] (layout in include/pcamv_gpu.h) -> int32 [n, 32]"""
+        req = np.ascontiguousarray(requests, np.uint8).reshape(-1, 1024)
+        out = np.zeros((len(req), 32), np.int32)
+        self.lib.pcamv_gpu_rd_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.pcamv_gpu_rd_probe(self.ctx, qp, len(req), _p(req), _p(out)), "rd_probe")
         return out
 
     def trace_mb(self, mb):

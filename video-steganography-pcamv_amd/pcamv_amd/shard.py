@@ -34,18 +34,14 @@ def gather_payloads(dist, local, n_gops, world, rank, device=None):
         return [local[g] for g in range(n_gops)]
     dev = device if device is not None else torch.device("cpu")
     per_rank = (n_gops + world - 1) // world
-    sizes = torch.zeros(per_rank, dtype=torch.int64, device=dev)
-    for k, g in enumerate(mine):
-        sizes[k] = len(local[g])
+    # operands are assembled on the host and moved once each: the device only sees the collectives themselves
+    sizes = torch.tensor([len(local[g]) for g in mine] + [0] * (per_rank - len(mine)), dtype=torch.int64).to(dev)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
-    cap = int(max(int(s.sum()) for s in all_sizes))
-    buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
-    off = 0
-    for g in mine:
-        b = torch.frombuffer(bytearray(local[g]), dtype=torch.uint8)
-        buf[off:off + len(b)] = b.to(dev)
-        off += len(b)
+    all_sizes = [s.cpu() for s in all_sizes]
+    cap = max(1, max(int(s.sum()) for s in all_sizes))
+    mine_bytes = b"".join(local[g] for g in mine)
+    buf = torch.frombuffer(bytearray(mine_bytes + bytes(cap - len(mine_bytes))), dtype=torch.uint8).to(dev)
     bucket = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, bucket, dst=0)
     if rank != 0:
