@@ -80,12 +80,20 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def tri(i, n):
+    """frame i of a clip of n frames played forwards, then backwards, then forwards ... (no cut anywhere: a cyclic clip jumps back by
+    its whole pan at the wrap, a scene change no encoder would code as a P frame)"""
+    period = 2 * n - 2
+    i %= period
+    return i if i < n else period - i
+
+
 class Gops:
     """closed-GOP pipelines on one device: contexts + batch + the step function.  phases[k] = frame of the (cyclic) clip GOP k starts at:
     the reference of its step 0 is that frame (standing in for the GOP's I picture), the source of its step t is frame phases[k] + t + 1"""
 
     def __init__(self, pcamv_amd, params, dframes, phases, device, closed_loop):
-        self.dframes, self.closed, self.phases = dframes, closed_loop, [int(ph) % len(dframes) for ph in phases]
+        self.dframes, self.closed, self.phases = dframes, closed_loop, [int(ph) % (2 * len(dframes) - 2) for ph in phases]
         self.encs = [pcamv_amd.Encoder(params, device=device) for _ in self.phases]
         self.batch = pcamv_amd.Batch(self.encs)
         if closed_loop:
@@ -100,12 +108,12 @@ class Gops:
             if self.closed and self.started:     # reference = this GOP's own deblocked reconstruction of the previous step, chained MV field
                 enc.set_ref_device(self.recon[k][0], self.recon[k][1], self.recon[k][2], enc.PREV_INTERNAL, enc.PREV_INTERNAL)
             elif self.closed:                    # a GOP's first P frame: the reference is an I picture, no motion field behind it
-                a = self.dframes[(t + ph) % nfr]
+                a = self.dframes[tri(t + ph, nfr)]
                 enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), 0, 0)
             else:
-                a = self.dframes[(t + ph) % nfr]
+                a = self.dframes[tri(t + ph, nfr)]
                 enc.set_ref_device(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enc.PREV_INTERNAL, enc.PREV_INTERNAL)
-            b = fenc_of(k) if fenc_of else [pl.data_ptr() for pl in self.dframes[(t + ph + 1) % nfr]]
+            b = fenc_of(k) if fenc_of else [pl.data_ptr() for pl in self.dframes[tri(t + ph + 1, nfr)]]
             enc.set_fenc_device(b[0], b[1], b[2])
         self.batch.step(qp, emrate, stream)
         self.started = True
@@ -171,9 +179,10 @@ def main():
     if G < 1:
         sys.exit(f"rank {rank}: no GOP to run (--strong --gops {args.gops} over {world} ranks)")
 
-    # synthetic clip (SURVEY 8(d) generator) of --classes frames, cycled; GOP g starts at frame g mod classes, so --classes
-    # content classes with different source pictures and motion histories are in flight (round 2 cycled 6 frames: 683 GOPs per class)
-    nfr = max(2, args.classes)
+    # synthetic clip (SURVEY 8(d) generator) played forwards and backwards (tri); GOP g starts at position g of that cycle, so
+    # --classes content classes with different source pictures and motion histories are in flight (round 2 cycled 6 frames: 683
+    # GOPs per class, and every sixth frame of a GOP jumped back by the clip's whole pan)
+    nfr = max(2, args.classes // 2 + 1)
     clip = make_clip(W, H, nfr, seed=13)
     dframes = [[torch.from_numpy(pl).to(dev) for pl in fr] for fr in clip]
     run = Gops(pcamv_amd, p, dframes, mine, local, closed_loop)
@@ -260,9 +269,9 @@ def main():
         def port_gop(k):
             t_c = time.perf_counter()
             o = orc.Oracle(op_par)
-            ph, prev, ref = run.phases[k], (None, None), clip[run.phases[k] % nfr]
+            ph, prev, ref = run.phases[k], (None, None), clip[tri(run.phases[k], nfr)]
             for t in range(T_done):
-                o.set_fenc(*clip[(t + ph + 1) % nfr])
+                o.set_fenc(*clip[tri(t + ph + 1, nfr)])
                 o.set_ref(*ref, *prev)
                 m_o, _ = o.analyse_pframe(args.qp, 1)
                 e_o = o.embed_pframe(m_o, args.emrate)
@@ -356,7 +365,7 @@ def main():
         "config": {"workload": f"BASELINE config 3: {W}x{H} synthetic I420, --me {args.me} --subme {args.subme} --qp {args.qp} --emrate {args.emrate}"
                                f"{' --no-cabac' if args.no_cabac else ''}, " + ("closed loop (pass 2 + loop filter on the GPU)" if closed_loop else "open-loop reference")
                                + (f", {args.gops} closed GOPs in total sharded over the ranks" if args.strong else f", {args.gops} closed GOPs in flight per GPU"),
-                   "mb_per_frame": n_mb, "gops_per_gpu": G, "frames_per_step": total_gops, "content_classes": min(nfr, total_gops),
+                   "mb_per_frame": n_mb, "gops_per_gpu": G, "frames_per_step": total_gops, "content_classes": min(2 * nfr - 2, total_gops),
                    "value_is": "inputs resident in HBM when the timed region starts; pcie_inclusive is the host-fed pipeline"},
         "extracted_payload_BER": ber, "BER_checked": {"gops": n_chk, "bits": ber_bits},
         "carriers_per_frame": int(emb["n"]), "bits_per_frame": int(emb["m"]),
@@ -393,7 +402,7 @@ def main():
         def upload(t, buf):
             with torch.cuda.stream(copy_st):
                 for k in range(G):
-                    dstage[buf][k].copy_(hsrc[(t + run.phases[k] + 1) % nfr], non_blocking=True)
+                    dstage[buf][k].copy_(hsrc[tri(t + run.phases[k] + 1, nfr)], non_blocking=True)
                 up_done[buf].record(copy_st)
 
         def fenc_of(buf):
@@ -426,8 +435,8 @@ def main():
         steady_ms = down_t[0].elapsed_time(down_t[nio - 1]) / (nio - 1) if nio > 1 else dth * 1e3
         t_next += args.host_io_steps
         got = np.frombuffer(h_out[0, :mb_bytes].numpy().tobytes(), dtype=np.uint8)
-        chk = np.asarray(run.encs[0].fetch_results(want_embed=False)[0]).view(np.uint8).reshape(-1)
-        if not np.array_equal(got, chk):
+        blocking = np.asarray(run.encs[0].fetch_results(want_embed=False)[0]).view(np.uint8).reshape(-1)
+        if not np.array_equal(got, blocking):
             sys.exit("bench.py: the records downloaded by the overlapped pipeline differ from the blocking fetch")
         out["pcie_inclusive"] = {"value": G * n_mb / (steady_ms * 1e-3), "unit": "MB/s", "ms_per_step": steady_ms,
                                  "steps": nio, "whole_pipeline_ms": dth * 1e3, "fill_and_drain_ms": dth * 1e3 - steady_ms * (nio - 1),
@@ -542,8 +551,8 @@ def main():
             tcpu, prev, ref = 0.0, (None, None), clip_[0]
             for t in range(frames):
                 if not closed_loop:
-                    ref = clip_[t % len(clip_)]
-                o.set_fenc(*clip_[(t + 1) % len(clip_)])
+                    ref = clip_[tri(t, len(clip_))]
+                o.set_fenc(*clip_[tri(t + 1, len(clip_))])
                 c0 = time.perf_counter()
                 o.set_ref(*ref, *prev)                      # plane production is part of the path
                 m_o, _ = o.analyse_pframe(args.qp, 1)
@@ -575,8 +584,8 @@ def main():
             tref, prev, ref = 0.0, (None, None), cclip[0]
             for t in range(args.cpu_cif_frames):
                 if not closed_loop:
-                    ref = cclip[t % nfr]
-                r.set_fenc(*cclip[(t + 1) % nfr])
+                    ref = cclip[tri(t, nfr)]
+                r.set_fenc(*cclip[tri(t + 1, nfr)])
                 c0 = time.perf_counter()
                 r.set_ref(*ref, *prev)
                 m_r, _ = r.analyse_pframe(args.qp)

@@ -19,7 +19,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pcamv_gpu.h but not exported"
-    assert lib.pcamv_gpu_abi_version() == 2     # round 2: i_psy_rd appended to pcamv_params_t, the debug state-hash entry points
+    assert lib.pcamv_gpu_abi_version() == 3     # round 3: rd_probe, NAL / bit-offset slice parsing, the speculative raster instance
 
 
 def test_no_cpu_fallback_without_a_device():

@@ -14,7 +14,10 @@
 #include "pcamv_host_tables.h"
 #include "pcamv_mvsyntax.h"
 
-#define PCAMV_ABI_VERSION 2
+#define PCAMV_ABI_VERSION 3
+#ifndef PCAMV_SPEC_MAX_CHAINS
+#define PCAMV_SPEC_MAX_CHAINS 256       /* chains in a batch up to which the speculative raster schedule is used (measured: DESIGN.md 4a) */
+#endif
 #define NEV 32
 #define NRING 8
 
@@ -33,7 +36,7 @@ struct pcamv_batch {
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
-    int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo;
+    int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo, rd_spec;
     int b_mbrd, b_tesa;         /* instance of the analysis kernel the batch's contexts need (fixed at creation) */
     unsigned *d_flow;
     FlowDev fl, fl2;          /* queue descriptors of the analysis and of the second pass */
@@ -83,6 +86,7 @@ extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 #ifdef PCAMV_PROF
 int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_lo(unsigned long long *out, int reset);
+int pcamv_rd_prof_fetch_spec(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
     unsigned long long rd[PCAMV_PROF_N];
@@ -91,6 +95,8 @@ extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
     if (pcamv_rd_prof_fetch(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     if (pcamv_rd_prof_fetch_lo(rd, reset)) return -1;
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
+    if (pcamv_rd_prof_fetch_spec(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     return 0;
 }
@@ -174,8 +180,9 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
     b->sched_flow = !(sched && !strcmp(sched, "diag")) && F.n_mb <= 65535 && n <= 65535;
     if (e == hipSuccess && b->sched_flow) {
         const size_t total = (size_t)n * F.n_mb;
-        e = dalloc(&b->d_flow, FLOW_CTR_WORDS + 2 * total);
+        e = dalloc(&b->d_flow, FLOW_CTR_WORDS + 2 * total + (size_t)FLOW_RDONE_STRIDE * n);
         b->fl.ctr = b->d_flow; b->fl.queue = b->d_flow + FLOW_CTR_WORDS; b->fl.dep = (int *)(b->d_flow + FLOW_CTR_WORDS + total);
+        b->fl.rdone = b->d_flow + FLOW_CTR_WORDS + 2 * total; b->fl.spec = 0;
         const char *aff = getenv("PCAMV_FLOW_AFFINITY");
         b->fl.nq = (aff && !strcmp(aff, "0")) || n < 8 ? 1 : 8;
         unsigned qb = 0;
@@ -195,7 +202,14 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
             /* measured (1080p umh subme 7, MB/s lo / hi): 256 chains 2.31 / 2.21 M, 512: 4.43 / 4.19 M, 1024: 6.84 / 7.77 M -- with one
              * wave per SIMD the lo build has no free wave left at 1024 chains to take the RCA steps off the chains */
             b->rd_lo = inst ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu);
-            per_cu = b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
+            /* ... and with few chains, the instance that hands a chain on speculatively after the 16x16 search (pcamv_rd_spec.hip:
+             * ~3 waves work on a chain then): PCAMV_FLOW_SPEC=0 / 1 overrides.  Needs pictures >= FLOW_SPEC_MIN_MBW macroblocks wide. */
+            const char *sp = getenv("PCAMV_FLOW_SPEC");
+            b->rd_spec = b->fl.raster && F.mb_w >= FLOW_SPEC_MIN_MBW && !(inst && strcmp(inst, "spec")) &&
+                         (sp ? atoi(sp) != 0 : (inst ? !strcmp(inst, "spec") : n <= PCAMV_SPEC_MAX_CHAINS));
+            if (b->rd_spec) b->rd_lo = 0;
+            b->fl.spec = b->rd_spec;
+            per_cu = b->rd_spec ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
             if (per_cu < 0) e = hipErrorUnknown;
         }
         const char *wv = getenv("PCAMV_FLOW_WAVES");
@@ -212,7 +226,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
          * its queue traffic is not what bounds it any more.  With thousands of GOPs in flight it is again: 4096 GOPs 2300 / 2277 /
          * 2264 / 2253 ms per step.  Default: 8 from 1024 GOPs on, else 1.  Same buffers: the two kernels never overlap. */
         { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : (n >= 1024 ? 8 : 1);
-          b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.raster = 0; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
+          b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.raster = 0; b->fl2.spec = 0; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
           b->fl2.total = (unsigned)n * (unsigned)b->fl2.n_mb;
           unsigned qb2 = 0;
           for (int q = 0; q < 8; q++) { b->fl2.qbase[q] = qb2; b->fl2.qcount[q] = b->fl.qcount[q] / (unsigned)F.n_mb * (unsigned)b->fl2.n_mb; qb2 += b->fl2.qcount[q]; }
@@ -504,7 +518,11 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         if (b->sched_flow) {
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
-            if (F.b_mbrd) { if (b->rd_lo) pcamv_launch_flow_rd_lo((unsigned)b->flow_waves, st, dF, b->fl); else pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl); }
+            if (F.b_mbrd) {
+                if (b->rd_spec) pcamv_launch_flow_rd_spec((unsigned)b->flow_waves, st, dF, b->fl);
+                else if (b->rd_lo) pcamv_launch_flow_rd_lo((unsigned)b->flow_waves, st, dF, b->fl);
+                else pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl);
+            }
             else if (tesa) pcamv_launch_flow_tesa((unsigned)b->flow_waves, st, dF, b->fl);
             else hipLaunchKernelGGL(k_analyse_flow, dim3(b->flow_waves), dim3(64), 0, st, dF, b->fl);
             if (timed) { hipEventRecord(b->ev1[ev], st); b->ev_head = (b->ev_head + 1) % NEV; if (b->ev_n < NEV) b->ev_n++; }

@@ -51,15 +51,7 @@ static __global__ void __launch_bounds__(256) k_chroma_pad(const FrameDev *__res
 }
 #endif
 
-/* clamp to [0,255] of an already shifted value.  The empty asm keeps hipcc (ROCm 7.2) from fusing
- * shift + clamp of two neighbours into v_ashr_pk_u8_i32: the code it emits around that gfx950
- * instruction ORs further bytes into the destination assuming bits [31:16] come back zero, but
- * the hardware leaves the old contents there (seen as wrong bytes 2/3 of every packed dword). */
-__device__ __forceinline__ uint32_t clamp_u8(int v)
-{
-    asm volatile("" : "+v"(v));
-    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-}
+/* (clamp_u8: pcamv_prims_gpu.h) */
 /* The four luma planes full / H / V / HV of the reference frame, padded (x264_frame_filter + expand_border,
  * common/mc.c:455-507, frame.c:246-300; the filtered planes are defined 4 columns / 8 rows beyond the picture and
  * replicated from there).  One thread = 4 horizontally adjacent output pixels, walking HP_ROWS rows down: it keeps
@@ -407,12 +399,17 @@ struct FlowDev {
     int unit;                 /* macroblocks of a row per task (second pass only; 1 by default); mb_w / n_mb above are in tasks */
     int raster;               /* --subme >= 6 with CABAC: the slice's context states chain the macroblocks of a frame in raster order
                                * (encoder.c:1900-1927, rdo.c:62), so a macroblock's only predecessor is the one coded before it */
+    int spec;                 /* raster chains handed on speculatively (mbk_search_spec below); the launcher picks the kernel instance */
+    unsigned *rdone;          /* [n_gop * FLOW_RDONE_STRIDE] per chain: macroblocks of the frame whose FINAL state is published */
 };
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define FLOW_HEAD(q) (64 * (q))
 #define FLOW_TAIL(q) (64 * (q) + 32)
 #define FLOW_ERR 512
 #define FLOW_CTR_WORDS 576
+#define FLOW_RDONE_STRIDE 32          /* words between two chains' counters: a 128-byte line each */
+#define FLOW_SPEC_AHEAD 4             /* a macroblock is handed on only once the one FLOW_SPEC_AHEAD before it is final */
+#define FLOW_SPEC_MIN_MBW 8           /* (so that its top / top-right neighbours, mb_w - 1 .. mb_w + 1 back, always are) */
 
 #ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
@@ -428,6 +425,7 @@ static __global__ void __launch_bounds__(256) k_flow_init(FlowDev fl)
     const unsigned k = i - fl.qbase[q], ngop_q = fl.qcount[q] / (unsigned)fl.n_mb;
     fl.queue[i] = k < ngop_q ? ((k * (unsigned)fl.nq + (unsigned)q) << 16) + 1u : 0u;
     if (i < 8) { fl.ctr[FLOW_HEAD(i)] = 0u; fl.ctr[FLOW_TAIL(i)] = fl.qcount[i] / (unsigned)fl.n_mb; }     /* heads 0, tails = GOPs of the queue; the error flag is the host's */
+    if (fl.spec && i < (unsigned)fl.n_gop) fl.rdone[FLOW_RDONE_STRIDE * i] = 0u;
 }
 #endif
 
@@ -438,6 +436,94 @@ __device__ __forceinline__ void flow_done_one(const FlowDev &fl, int q, int slot
         unsigned t = __hip_atomic_fetch_add(&fl.ctr[FLOW_TAIL(q)], 1u, RLX_AGENT);
         __hip_atomic_store(&fl.queue[fl.qbase[q] + t], item, RLX_AGENT);
     }
+}
+
+
+/* ------------------------------------------------------------------ speculative hand-off along a raster chain
+ * With CABAC a frame is ONE chain of macroblocks (the context states), and with few GOPs in flight the chip waits for that
+ * chain: ~100 us per macroblock, of which the 16x16 search is a third.  What the NEXT macroblock's searches need from this
+ * one is its motion only (the left column of its 4x4 motion field, its 16x16 search result, whether it is skipped) -- the
+ * entropy coder's state is first read by the RD stage.  And the motion is almost always the 16x16 result (or the skip
+ * prediction).  So a macroblock publishes "16x16, this MV" (or its skip) right after its 16x16 search and hands the chain on;
+ * its other searches, its RD stage and the successor's searches then run side by side on different waves.  Exact by
+ * construction: before its RD stage every macroblock waits until its predecessor is FINAL (rdone), compares the motion it
+ * started from with the final one, and starts over if they differ (so does, in turn, whoever started from what it published);
+ * what a macroblock commits is computed from verified inputs only.  A macroblock is handed on only once the macroblock
+ * FLOW_SPEC_AHEAD before it is final, which keeps the top neighbours (>= mb_w - 1 back) out of the speculation.
+ * Waits are on waves that are running and never wait for a younger macroblock: no cycle; all spins are bounded. */
+__device__ __forceinline__ bool flow_wait_rdone(const FlowDev &fl, int g, unsigned need)
+{
+    if (!need) return true;
+    const unsigned *p = fl.rdone + FLOW_RDONE_STRIDE * g;
+    for (unsigned spins = 0;; spins++) {
+        unsigned v = 0;
+        if (LANE() == 0) v = __hip_atomic_load(p, RLX_AGENT);
+        if (flow_bcast(v) >= need) return true;
+        unsigned bad = 0;
+        if ((spins & 255u) == 255u) { if (LANE() == 0) bad = __hip_atomic_load(&fl.ctr[FLOW_ERR], RLX_AGENT); bad = flow_bcast(bad); }
+        if (bad || spins >= fl.spin_limit) { if (LANE() == 0) __hip_atomic_store(&fl.ctr[FLOW_ERR], 1u, RLX_AGENT); return false; }
+        if (spins < 16) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+    }
+}
+/* the left neighbour's motion as this macroblock's searches used it (from the cache and the candidate list: the very values
+ * they consumed), and as it is now in memory; equal = the searches stand */
+__device__ __forceinline__ bool spec_inputs_final(const FrameDev &F, MBLocal *L)
+{
+    if (!(L->neighbour & NB_LEFT)) return true;
+    const int xy = L->mb_xy, s4 = 4 * F.mb_w, b4 = 4 * (L->mb_y * s4 + L->mb_x);
+    const uint32_t m0 = NB_LD32(&F.mv[2 * (b4 - 1)]), m1 = NB_LD32(&F.mv[2 * (b4 - 1 + s4)]);
+    const uint32_t m2 = NB_LD32(&F.mv[2 * (b4 - 1 + 2 * s4)]), m3 = NB_LD32(&F.mv[2 * (b4 - 1 + 3 * s4)]);
+    const uint32_t r = NB_LD32(&F.mvr[2 * (xy - 1)]);
+    const int t = NB_LD8(&F.mb_type[xy - 1]);
+    PCAMV_WAVE_SYNC();
+    const int16_t (*c)[2] = L->cmv;
+    bool ok = m0 == NB_PACK16(c[SCAN8_0 - 1][0], c[SCAN8_0 - 1][1]) && m1 == NB_PACK16(c[SCAN8_0 - 1 + 8][0], c[SCAN8_0 - 1 + 8][1]) &&
+              m2 == NB_PACK16(c[SCAN8_0 - 1 + 16][0], c[SCAN8_0 - 1 + 16][1]) && m3 == NB_PACK16(c[SCAN8_0 - 1 + 24][0], c[SCAN8_0 - 1 + 24][1]);
+    ok = ok && (t == PCAMV_P_SKIP) == (L->type_left == PCAMV_P_SKIP);
+    /* a coded left neighbour's 16x16 result is the first candidate of this macroblock's 16x16 search (predict_mv_ref16x16) */
+    if (t != PCAMV_P_SKIP) ok = ok && r == NB_PACK16(L->mvc16[0][0], L->mvc16[0][1]);
+    return flow_bcast(ok ? 1u : 0u) != 0u;
+}
+template <int TESA>
+__device__ __forceinline__ bool mbk_search_spec(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y, const FlowDev &fl, int g, unsigned item)
+{
+    const int xy = mb_y * F.mb_w + mb_x, lane = LANE();
+    const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
+    bool handed_on = false;
+    int skip;
+    for (int round = 0;; round++) {
+        mb_load(F, L, mb_x, mb_y, 0, 0);                 /* neighbours' motion + source pixels; nothing of the entropy coder yet */
+        skip = analyse_s16<TESA>(F, L, a);
+        if (!handed_on) {
+            /* what the successor's searches start from: a skipped macroblock's motion is final as it stands (as far as this
+             * macroblock's own inputs are), a coded one is announced as 16x16 with the search's result */
+            const uint32_t w = skip ? NB_PACK16(L->pskip_mv[0], L->pskip_mv[1]) : NB_PACK16(a->me16x16.mv[0], a->me16x16.mv[1]);
+            if (lane < 16) NB_ST32(&F.mv[2 * (b4 + (lane >> 2) * s4 + (lane & 3))], w);
+            if (lane == 0) { NB_ST8(&F.mb_type[xy], skip ? PCAMV_P_SKIP : PCAMV_P_L0); NB_ST16(&F.ref8[b8], 0); NB_ST16(&F.ref8[b8 + s8], 0); }
+            if (xy + 1 < fl.n_mb) {
+                if (!flow_wait_rdone(fl, g, xy + 1 > FLOW_SPEC_AHEAD ? (unsigned)(xy + 1 - FLOW_SPEC_AHEAD) : 0u)) return false;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) flow_done_one(fl, g & (fl.nq - 1), g * fl.n_mb + xy + 1, item + 1u);
+            }
+            handed_on = true;
+        }
+        if (!skip) analyse_s_rest<TESA>(F, L, a);
+        if (!flow_wait_rdone(fl, g, (unsigned)xy)) return false;         /* the macroblock coded before this one is final */
+        if (spec_inputs_final(F, L)) break;
+        if (round >= 64) { if (lane == 0) __hip_atomic_store(&fl.ctr[FLOW_ERR], 1u, RLX_AGENT); return false; }     /* (cannot happen: the predecessor is final now) */
+    }
+    /* RD stage: the entropy coder's neighbourhood, the intra borders and the context states as the predecessor left them */
+    {
+        MbFetch pf;
+        prim_mb_fetch(F, mb_x, mb_y, L->neighbour, 1, pf);
+        prim_mb_fetch_store(F, L, 1, pf);
+    }
+    if (!skip) analyse_decide<TESA>(F, L, a);
+    update_cache(L, a);
+    mbk_search_finish<TESA>(F, L, a, mb_x, mb_y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(fl.rdone + FLOW_RDONE_STRIDE * g, (unsigned)(xy + 1), RLX_AGENT);
+    return true;
 }
 
 #ifndef PCAMV_FLOW_OCC
@@ -506,7 +592,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
 #ifdef PCAMV_SEARCH_CALL
         if (MODE == 0 && lane == 0) L.fdesc = Fs + g;
 #endif
-        if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
+        if (MODE == 0 && (TESA & 4)) { if (!mbk_search_spec<TESA>(F, &L, Ap, x, y, fl, g, item)) break; }
+        else if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
         else {
             for (int k = 0; k < fl.unit; k++) {
                 const int mx = fl.unit * x + k;
@@ -523,7 +610,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
          * have drained, the counters / queue entries may follow -- no agent-scope release (it would write back the
          * XCD's whole dirty L2 once per macroblock: measured 13.3 -> 19.9 M MB/s without it) */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && fl.raster) {
+        if (MODE == 0 && (TESA & 4)) { }                    /* the speculative chain hands on inside mbk_search_spec */
+        else if (lane == 0 && fl.raster) {
             if (xy + 1 < fl.n_mb) flow_done_one(fl, g & (fl.nq - 1), g * fl.n_mb + xy + 1, item + 1u);
         } else if (lane == 0) {
             const int base = g * fl.n_mb, q = g & (fl.nq - 1);
@@ -576,17 +664,22 @@ void pcamv_launch_flow_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, 
 #ifndef PCAMV_RD_OCC
 #define PCAMV_RD_OCC 4
 #endif
+#ifndef PCAMV_RD_VARIANT
+#define PCAMV_RD_VARIANT 2        /* variant mask of the control code: 2 = RD mode decision, 2 | 4 = ... with the speculative raster chain */
+#endif
 static __global__ void __launch_bounds__(64, PCAMV_RD_OCC) k_analyse_flow_rd(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
     __shared__ MBLocal L;
     __shared__ Analysis A;
-    flow_loop<0, 2>(Fs, fl, L, &A, nullptr);
+    flow_loop<0, PCAMV_RD_VARIANT>(Fs, fl, L, &A, nullptr);
 }
 #endif
 void pcamv_launch_flow_rd(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu(void);
 void pcamv_launch_flow_rd_lo(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu_lo(void);
+void pcamv_launch_flow_rd_spec(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu_spec(void);
 
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the

@@ -633,6 +633,8 @@ struct Analysis {
     int mvc[5][2];
     int cost8x8, cost16x8, cost8x16, cost4x4[4], cost8x4[4], cost4x8[4];
     int rd16x16;
+    int rd16_early;                /* the 16x16 search ended on the skip MV: its RD trial is made whatever the thresholds say (analyse.c:1194-1203) */
+    int sel_type, sel_part, sel_cost;      /* the decision by SATD cost (analyse.c:2653-2743), input of the refinement / RD stage */
 };
 PCAMV_DEV void me_setup(MEState *me, int ip, int xoff, int yoff) { me->i_pixel = ip; me->xoff = xoff; me->yoff = yoff; me->cost = me->cost_mv = me->cost_rec = 0; me->mv[0] = me->mv[1] = 0; me->mvp[0] = me->mvp[1] = 0; }
 
@@ -875,11 +877,10 @@ PCAMV_DEV int analyse_p16x16(const FrameDev &F, MBLocal *L, Analysis *a, int b_t
     L->i_type = PCAMV_P_L0;
     if (MBRD_ON) {                                   /* analyse.c:1194-1203 */
         prim_fenc_complexity(F, L);
-        if (me.mv[0] == L->pskip_mv[0] && me.mv[1] == L->pskip_mv[1]) {
-            L->i_partition = PCAMV_D_16x16;
-            cache_mv_set(L, 0, 0, 4, 4, me.mv[0], me.mv[1]);
-            a->rd16x16 = rd_trial(F, L, 1);
-        }
+        /* the reference makes this trial here; nothing the searches that follow read depends on it (it only sets i_rd16x16), so it
+         * is made at the head of the RD stage (analyse_decide), which keeps everything that needs the entropy coder's state of the
+         * macroblock coded before this one -- the chain from macroblock to macroblock -- in one place behind the searches */
+        a->rd16_early = me.mv[0] == L->pskip_mv[0] && me.mv[1] == L->pskip_mv[1];
     }
     return 0;
 }
@@ -1097,92 +1098,123 @@ PCAMV_DEV int carrier_of_block(int i_type, int i_partition, const uint8_t *sub, 
 /* ---------------------------------------------------------------- phase A: search + decision */
 /* Analyse one macroblock (motion search, partition decision, early skip) and publish its final
  * motion to the frame arrays its right/lower neighbours read.  Writes the record without the
- * RCA fields; the search-time mvp of every carrier slot goes to mvp_aux for phase B. */
+ * RCA fields; the search-time mvp of every carrier slot goes to mvp_aux for phase B.
+ * Three stages, so that a schedule can hand the macroblock's successor its motion as early as it is known (the speculative
+ * raster schedule of the RD instance, pcamv_kernels.hip.h):
+ *   analyse_s16     early P_SKIP, else the 16x16 search (returns 1 for a skipped macroblock: nothing else follows)
+ *   analyse_s_rest  the other partitions' searches and the decision by SATD cost
+ *   analyse_decide  quarter-pel refinement of the decided partition, or -- --subme >= 6 -- the intra thresholds and the RD trials:
+ *                   the only stage that reads what the entropy coder left behind in the macroblock coded before this one */
 template <int TESA>
-PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
+PCAMV_DEV int analyse_s16(const FrameDev &F, MBLocal *L, Analysis *a)
 {
-    int b_skip = 0, b_try_pskip = 0, i_cost;
-    unsigned flags = F.inter;
-    const unsigned long long t_a = PROF_T();
+    int b_skip = 0, b_try_pskip = 0;
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
     L->i_partition = PCAMV_D_16x16;
     a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = PCAMV_COST_MAX;      /* analyse.c:321-332 */
+    a->rd16_early = 0;
     L->snap_part = -1; L->snap_cost = PCAMV_COST_MAX;
     if (F.b_fast_pskip) {
         if (F.subme >= 3) b_try_pskip = 1;
         else if (L->type_left == PCAMV_P_SKIP || L->type_top == PCAMV_P_SKIP || L->type_topleft == PCAMV_P_SKIP || L->type_topright == PCAMV_P_SKIP)
             b_skip = probe_pskip(F, L);
     }
-    if (b_skip) { L->i_type = PCAMV_P_SKIP; L->i_partition = PCAMV_D_16x16; }
-    else if (!analyse_p16x16<TESA>(F, L, a, b_try_pskip)) {
-        PROF_ADD(6, t_a);
-        int i_type = PCAMV_P_L0, i_partition = PCAMV_D_16x16;
-        const unsigned long long t_b = PROF_T();
-        if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8<TESA>(F, L, a);
-        PROF_ADD(7, t_b);
-        const unsigned long long t_c = PROF_T();
-        i_cost = a->me16x16.cost;
-        if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost) {
-            if (flags & PCAMV_ANALYSE_PSUB8x8) {
-                i_type = PCAMV_P_8x8; i_partition = PCAMV_D_8x8; i_cost = a->cost8x8;
-                for (int i = 0; i < 4; i++) {
-                    analyse_sub8x8<TESA>(F, L, a, i, PIX_4x4);
-                    if (a->cost4x4[i] < a->me8x8[i].cost) {
-                        int c8 = a->cost4x4[i];
-                        L->sub_part[i] = PCAMV_D_L0_4x4;
-                        analyse_sub8x8<TESA>(F, L, a, i, PIX_8x4);
-                        if (a->cost8x4[i] < c8) { c8 = a->cost8x4[i]; L->sub_part[i] = PCAMV_D_L0_8x4; }
-                        analyse_sub8x8<TESA>(F, L, a, i, PIX_4x8);
-                        if (a->cost4x8[i] < c8) { c8 = a->cost4x8[i]; L->sub_part[i] = PCAMV_D_L0_4x8; }
-                        i_cost += c8 - a->me8x8[i].cost;
-                    }
-                    cache_mv_p8x8(L, a, i);
+    if (b_skip) { L->i_type = PCAMV_P_SKIP; L->i_partition = PCAMV_D_16x16; return 1; }
+    return analyse_p16x16<TESA>(F, L, a, b_try_pskip);
+}
+template <int TESA>
+PCAMV_DEV void analyse_s_rest(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    int i_cost;
+    const unsigned flags = F.inter;
+    int i_type = PCAMV_P_L0, i_partition = PCAMV_D_16x16;
+    const unsigned long long t_b = PROF_T();
+    if (flags & PCAMV_ANALYSE_PSUB16x16) analyse_p8x8<TESA>(F, L, a);
+    PROF_ADD(7, t_b);
+    const unsigned long long t_c = PROF_T();
+    i_cost = a->me16x16.cost;
+    if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost) {
+        if (flags & PCAMV_ANALYSE_PSUB8x8) {
+            i_type = PCAMV_P_8x8; i_partition = PCAMV_D_8x8; i_cost = a->cost8x8;
+            for (int i = 0; i < 4; i++) {
+                analyse_sub8x8<TESA>(F, L, a, i, PIX_4x4);
+                if (a->cost4x4[i] < a->me8x8[i].cost) {
+                    int c8 = a->cost4x4[i];
+                    L->sub_part[i] = PCAMV_D_L0_4x4;
+                    analyse_sub8x8<TESA>(F, L, a, i, PIX_8x4);
+                    if (a->cost8x4[i] < c8) { c8 = a->cost8x4[i]; L->sub_part[i] = PCAMV_D_L0_8x4; }
+                    analyse_sub8x8<TESA>(F, L, a, i, PIX_4x8);
+                    if (a->cost4x8[i] < c8) { c8 = a->cost4x8[i]; L->sub_part[i] = PCAMV_D_L0_4x8; }
+                    i_cost += c8 - a->me8x8[i].cost;
                 }
-                a->cost8x8 = i_cost;
+                cache_mv_p8x8(L, a, i);
             }
+            a->cost8x8 = i_cost;
         }
-        if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost + a->me8x8[1].cost_mv + a->me8x8[2].cost_mv) {
-            analyse_p16x8<TESA>(F, L, a);
-            if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x8; }
-            analyse_p8x16<TESA>(F, L, a);
-            if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
+    }
+    if ((flags & PCAMV_ANALYSE_PSUB16x16) && a->cost8x8 < a->me16x16.cost + a->me8x8[1].cost_mv + a->me8x8[2].cost_mv) {
+        analyse_p16x8<TESA>(F, L, a);
+        if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x8; }
+        analyse_p8x16<TESA>(F, L, a);
+        if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_type = PCAMV_P_L0; i_partition = PCAMV_D_8x16; }
+    }
+    L->i_partition = i_partition;
+    a->sel_type = i_type; a->sel_part = i_partition; a->sel_cost = i_cost;
+    PROF_ADD(8, t_c);
+}
+template <int TESA>
+PCAMV_DEV void analyse_decide(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    int i_type = a->sel_type, i_partition = a->sel_part, i_cost = a->sel_cost;
+    const unsigned long long t_d = PROF_T();
+    if (MBRD_ON) {
+        /* analyse.c:2749-2752, 2809-2850: no quarter-pel refinement; the intra SATD cost (never an intra mode: analyse.c:2863)
+         * bounds the RD trials; x264_rd_cost_mb decides the partition; P_8x8 only while embedding (analyse.c:2841) */
+        int i16, i4;
+        if (a->rd16_early) {                 /* analyse.c:1197-1202, see analyse_p16x16 */
+            L->i_type = PCAMV_P_L0; L->i_partition = PCAMV_D_16x16;
+            cache_mv_set(L, 0, 0, 4, 4, a->me16x16.mv[0], a->me16x16.mv[1]);
+            a->rd16x16 = rd_trial(F, L, 1);
         }
+        const unsigned long long t_i = PROF_T();
+        if (F.b_chroma_me) {
+            const int c8 = intra_chroma_cost(F, L);
+            intra_analyse(F, L, i_cost - c8, &i16, &i4);
+            i16 += c8; i4 += c8;
+        } else intra_analyse(F, L, i_cost, &i16, &i4);
+        PROF_ADD(16, t_i);
+        const unsigned long long t_rd = PROF_T();
+        analyse_p_rd(F, L, a, imin(i_cost, imin(i16, i4)));
+        PROF_ADD(17, t_rd);
+        i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x16; i_cost = a->me16x16.cost;
+        if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = PCAMV_D_16x8; }
+        if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_partition = PCAMV_D_8x16; }
+        if (F.embed && a->cost8x8 < i_cost) { i_cost = a->cost8x8; i_partition = PCAMV_D_8x8; i_type = PCAMV_P_8x8; }
         L->i_partition = i_partition;
-        PROF_ADD(8, t_c);
-        const unsigned long long t_d = PROF_T();
-        if (MBRD_ON) {
-            /* analyse.c:2749-2752, 2809-2850: no quarter-pel refinement; the intra SATD cost (never an intra mode: analyse.c:2863)
-             * bounds the RD trials; x264_rd_cost_mb decides the partition; P_8x8 only while embedding (analyse.c:2841) */
-            int i16, i4;
-            const unsigned long long t_i = PROF_T();
-            if (F.b_chroma_me) {
-                const int c8 = intra_chroma_cost(F, L);
-                intra_analyse(F, L, i_cost - c8, &i16, &i4);
-                i16 += c8; i4 += c8;
-            } else intra_analyse(F, L, i_cost, &i16, &i4);
-            PROF_ADD(16, t_i);
-            const unsigned long long t_rd = PROF_T();
-            analyse_p_rd(F, L, a, imin(i_cost, imin(i16, i4)));
-            PROF_ADD(17, t_rd);
-            i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x16; i_cost = a->me16x16.cost;
-            if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = PCAMV_D_16x8; }
-            if (a->cost8x16 < i_cost) { i_cost = a->cost8x16; i_partition = PCAMV_D_8x16; }
-            if (F.embed && a->cost8x8 < i_cost) { i_cost = a->cost8x8; i_partition = PCAMV_D_8x8; i_type = PCAMV_P_8x8; }
-            L->i_partition = i_partition;
-        } else
-        if (i_partition == PCAMV_D_16x16) me_refine_qpel<TESA>(F, L, &a->me16x16);
-        else if (i_partition == PCAMV_D_16x8) { me_refine_qpel<TESA>(F, L, &a->me16x8[0]); me_refine_qpel<TESA>(F, L, &a->me16x8[1]); }
-        else if (i_partition == PCAMV_D_8x16) { me_refine_qpel<TESA>(F, L, &a->me8x16[0]); me_refine_qpel<TESA>(F, L, &a->me8x16[1]); }
-        else
-            for (int i = 0; i < 4; i++)
-                switch (L->sub_part[i]) {
-                case PCAMV_D_L0_8x8: me_refine_qpel<TESA>(F, L, &a->me8x8[i]); break;
-                case PCAMV_D_L0_8x4: me_refine_qpel<TESA>(F, L, &a->me8x4[i][0]); me_refine_qpel<TESA>(F, L, &a->me8x4[i][1]); break;
-                case PCAMV_D_L0_4x8: me_refine_qpel<TESA>(F, L, &a->me4x8[i][0]); me_refine_qpel<TESA>(F, L, &a->me4x8[i][1]); break;
-                default: for (int k = 0; k < 4; k++) me_refine_qpel<TESA>(F, L, &a->me4x4[i][k]); break;
-                }
-        L->i_type = i_type;
-        PROF_ADD(9, t_d);
+    } else
+    if (i_partition == PCAMV_D_16x16) me_refine_qpel<TESA>(F, L, &a->me16x16);
+    else if (i_partition == PCAMV_D_16x8) { me_refine_qpel<TESA>(F, L, &a->me16x8[0]); me_refine_qpel<TESA>(F, L, &a->me16x8[1]); }
+    else if (i_partition == PCAMV_D_8x16) { me_refine_qpel<TESA>(F, L, &a->me8x16[0]); me_refine_qpel<TESA>(F, L, &a->me8x16[1]); }
+    else
+        for (int i = 0; i < 4; i++)
+            switch (L->sub_part[i]) {
+            case PCAMV_D_L0_8x8: me_refine_qpel<TESA>(F, L, &a->me8x8[i]); break;
+            case PCAMV_D_L0_8x4: me_refine_qpel<TESA>(F, L, &a->me8x4[i][0]); me_refine_qpel<TESA>(F, L, &a->me8x4[i][1]); break;
+            case PCAMV_D_L0_4x8: me_refine_qpel<TESA>(F, L, &a->me4x8[i][0]); me_refine_qpel<TESA>(F, L, &a->me4x8[i][1]); break;
+            default: for (int k = 0; k < 4; k++) me_refine_qpel<TESA>(F, L, &a->me4x4[i][k]); break;
+            }
+    L->i_type = i_type;
+    PROF_ADD(9, t_d);
+}
+template <int TESA>
+PCAMV_DEV void analyse_mb_search(const FrameDev &F, MBLocal *L, Analysis *a)
+{
+    const unsigned long long t_a = PROF_T();
+    const int skip = analyse_s16<TESA>(F, L, a);
+    PROF_ADD(6, t_a);
+    if (!skip) {
+        analyse_s_rest<TESA>(F, L, a);
+        analyse_decide<TESA>(F, L, a);
     }
     update_cache(L, a);
 }

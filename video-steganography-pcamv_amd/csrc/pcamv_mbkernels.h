@@ -20,13 +20,11 @@
 #define PCAMV_LANE0 (LANE() == 0)
 #endif
 
+/* what follows the decision: (--subme >= 6) the pass-1 reconstruction and the entropy coder's bookkeeping, then the record and the
+ * macroblock's final motion, written through for the neighbours */
 template <int TESA>
-PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
+PCAMV_DEV void mbk_search_finish(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
 {
-    const unsigned long long t_l = PROF_T();
-    mb_load(F, L, mb_x, mb_y, 0, MBRD_ON);
-    PROF_ADD(11, t_l);
-    analyse_mb_search<TESA>(F, L, a);
     if (MBRD_ON) {
         /* --subme >= 6: the macroblock as coded is part of what its neighbours read (reconstructed pixels for the intra
          * thresholds, non-zero flags / coded block pattern / MV differences / context states for the bit counts), so the
@@ -80,6 +78,15 @@ PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, 
         NB_ST16(&F.ref8[b8 + s8], (uint16_t)(uint8_t)L->cref[scan8_of(8)] | (uint16_t)(uint8_t)L->cref[scan8_of(12)] << 8);
     }
     PROF_ADD(12, t_w);
+}
+template <int TESA>
+PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
+{
+    const unsigned long long t_l = PROF_T();
+    mb_load(F, L, mb_x, mb_y, 0, MBRD_ON);
+    PROF_ADD(11, t_l);
+    analyse_mb_search<TESA>(F, L, a);
+    mbk_search_finish<TESA>(F, L, a, mb_x, mb_y);
 }
 
 /* rebuild the decided partitioning (types, MVs, search-time mvp) from the record */

@@ -28,6 +28,16 @@ __device__ __forceinline__ int pcamv_lane_id(void) { int l = (int)(threadIdx.x &
 #else
 #define LANE() pcamv_lane_id()
 #endif
+/* clamp to [0,255] of an already shifted value.  The empty asm keeps hipcc (ROCm 7.2) from fusing
+ * shift + clamp of two neighbours into v_ashr_pk_u8_i32: the code it emits around that gfx950
+ * instruction ORs further bytes into the destination assuming bits [31:16] come back zero, but
+ * the hardware leaves the old contents there (seen as wrong bytes 2/3 of every packed dword: first in k_hpel, in round 3 by the
+ * predictor probe in the plane predictors of the intra analysis, whose values can leave [0,255] before the clamp). */
+__device__ __forceinline__ uint32_t clamp_u8(int v)
+{
+    asm volatile("" : "+v"(v));
+    return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t lds4(const uint8_t *p) { return *(const uint32_t *)p; }
 __device__ __forceinline__ void sts4(uint8_t *p, uint32_t v) { *(uint32_t *)p = v; }

@@ -150,7 +150,7 @@ __device__ __forceinline__ void prim_intra16_satd(const FrameDev &F, MBLocal *L,
         for (int y = 0; y < 4; y++) {
             uint32_t o = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + mul24s(b, px + x - 7) + mul24s(c, py + y - 7) + 16) >> 5, 0, 255) << (8 * x);
+            for (int x = 0; x < 4; x++) o |= clamp_u8((a + mul24s(b, px + x - 7) + mul24s(c, py + y - 7) + 16) >> 5) << (8 * x);
             r[y] = o;
         }
     }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void prim_intra8c_satd(const FrameDev &F, MBLocal *L,
             for (int y = 0; y < 4; y++) {
                 uint32_t o = 0;
 #pragma unroll
-                for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((a + mul24s(b, px + x - 3) + mul24s(c, py + y - 3) + 16) >> 5, 0, 255) << (8 * x);
+                for (int x = 0; x < 4; x++) o |= clamp_u8((a + mul24s(b, px + x - 3) + mul24s(c, py + y - 3) + 16) >> 5) << (8 * x);
                 r[y] = o;
             }
         }

@@ -22,7 +22,12 @@
 #ifndef PCAMV_NO_RESIDUAL_CALL
 #define PCAMV_RESIDUAL_CALL 1      /* pcamv_prims_rd_gpu.h: the CABAC residual walk as a function of its own */
 #endif
-#ifdef PCAMV_RD_LO
+#if defined(PCAMV_RD_SPEC)          /* pcamv_rd_spec.hip: the speculative raster chain for few GOPs in flight, one wave per SIMD */
+#define PCAMV_RD_LO 1
+#define PCAMV_RD_OCC 1
+#define PCAMV_RD_VARIANT 6
+#define RD_NAME(x) x##_spec
+#elif defined(PCAMV_RD_LO)
 #define PCAMV_RD_OCC 1
 #define RD_NAME(x) x##_lo
 #else
