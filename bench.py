@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--parity-gops", type=int, default=8, help="GOPs compared with the CPU port after the timed loop (the first of every XCD queue; 0 = skip)")
     ap.add_argument("--clip-keyints", default="30,8", help="keyint values of the 600-frame clip block ('' = skip; rank 0, N=1 only)")
     ap.add_argument("--clip-frames", type=int, default=600)
-    ap.add_argument("--g-sweep", default="1,8,20,64,256", help="GOP counts of the low-G sweep ('' = skip; rank 0, N=1 only)")
+    ap.add_argument("--g-sweep", default="1,8,20,64,256,1024,2048", help="GOP counts of the low-G sweep ('' = skip; rank 0, N=1 only)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="1080p P frames timed for the CPU baseline (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-cif-frames", type=int, default=200, help="CIF P frames timed through the reference itself (oracle/_ref) and through the port (0 = skip)")
     return ap.parse_args()
@@ -266,10 +266,12 @@ def main():
         op_par = orc.make_params(W, H, me=args.me, subme=args.subme, mv_range=p.i_mv_range, tscale=256, inter=p.inter, cabac=p.b_cabac)
         assert (op_par.i_psy_rd, op_par.i_chroma_qp_offset) == (p.i_psy_rd, p.i_chroma_qp_offset)
 
+        phases_par = list(run.phases)
+
         def port_gop(k):
             t_c = time.perf_counter()
             o = orc.Oracle(op_par)
-            ph, prev, ref = run.phases[k], (None, None), clip[tri(run.phases[k], nfr)]
+            ph, prev, ref = phases_par[k], (None, None), clip[tri(phases_par[k], nfr)]
             for t in range(T_done):
                 o.set_fenc(*clip[tri(t + ph + 1, nfr)])
                 o.set_ref(*ref, *prev)
@@ -301,6 +303,7 @@ def main():
             hi = min(G, lo + 256)
             same = same and bool((d_all[lo:hi, mb_bytes_:] == d_all[idx_first[lo:hi], mb_bytes_:]).all().item())
         del d_all, n_car
+        torch.cuda.empty_cache()
         if not same:
             sys.exit("bench.py: GOPs of the same content class ended the timed loop with different records / flip maps")
         parity = {"gops_identical_within_class": True, "content_classes": len(first_of), "gops": G}
@@ -448,6 +451,12 @@ def main():
                                          "next one's, averaged over the pipeline's steps); fill_and_drain_ms = the first step's upload + compute + "
                                          "download that nothing overlaps"}
         del dstage, d_out, h_out, hsrc
+
+    # the main set of GOPs is done with (its results were fetched above): its HBM goes to the runs below
+    if solo:
+        run.close()
+        run = None
+        torch.cuda.empty_cache()
 
     # ---- throughput against the number of GOPs in flight (extra): a frame's macroblocks form one chain, so few GOPs = few busy waves
     if solo and args.g_sweep:
@@ -610,7 +619,8 @@ def main():
         out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out))
-    run.close()
+    if run is not None:
+        run.close()
     if dist is not None:
         dist.destroy_process_group()
 

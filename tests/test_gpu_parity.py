@@ -690,11 +690,11 @@ def test_config5_2160p_esa(pc):
     assert _closed_loop_vs_oracle(pc, 3840, 2160, "esa", 6, 26, 1, 1, 17, statics=(1920,)) > 4000
 
 
-@pytest.mark.parametrize("inst", ["hi", "lo", "spec"])
+@pytest.mark.parametrize("inst", ["hi", "lo", "spec", "spec2", "spec4"])
 def test_rd_instances_agree(pc, monkeypatch, inst):
-    """the RD instance has three builds (pcamv_rd.hip): few chains run the one that hands a chain on speculatively after the 16x16
-    search (one wave per SIMD; the default of every small test here), more the plain one-wave-per-SIMD build, thousands the one
-    with 4 waves per SIMD; here each is forced onto the same small batches: CABAC (one chain per frame) closed loop, then the
+    """the RD instance has five builds (pcamv_rd*.hip): the ones that hand a chain on speculatively after the 16x16 search at 1 (the
+    default of every small test here), 2 and 4 waves per SIMD, chosen by the number of chains, and the plain ones at 1 and 4 waves
+    per SIMD (no chain to speculate on -- CAVLC --, or thousands of chains); here each is forced onto the same small batches: CABAC (one chain per frame) closed loop, then the
     CAVLC sizes (wavefront order: no chain to speculate on, "spec" falls back) and a noisy CABAC case through the sweep"""
     monkeypatch.setenv("PCAMV_RD_INSTANCE", inst)
     assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 3, 2, 71, hashes=True) > 0

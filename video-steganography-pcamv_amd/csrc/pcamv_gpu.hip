@@ -15,9 +15,11 @@
 #include "pcamv_mvsyntax.h"
 
 #define PCAMV_ABI_VERSION 3
-#ifndef PCAMV_SPEC_MAX_CHAINS
-#define PCAMV_SPEC_MAX_CHAINS 256       /* chains in a batch up to which the speculative raster schedule is used (measured: DESIGN.md 4a) */
-#endif
+/* chains in a batch up to which the speculative raster schedule is used, and up to which its 1 / 2 waves-per-SIMD builds (measured:
+ * pcamv_gpu_batch_create) */
+#define PCAMV_SPEC_MAX_CHAINS 3584
+#define PCAMV_SPEC1_MAX_CHAINS 320
+#define PCAMV_SPEC2_MAX_CHAINS 704
 #define NEV 32
 #define NRING 8
 
@@ -87,6 +89,8 @@ extern "C" int pcamv_gpu_abi_version(void) { return PCAMV_ABI_VERSION; }
 int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_lo(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_spec(unsigned long long *out, int reset);
+int pcamv_rd_prof_fetch_spec2(unsigned long long *out, int reset);
+int pcamv_rd_prof_fetch_spec4(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
     unsigned long long rd[PCAMV_PROF_N];
@@ -97,6 +101,10 @@ extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
     if (pcamv_rd_prof_fetch_lo(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     if (pcamv_rd_prof_fetch_spec(rd, reset)) return -1;
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
+    if (pcamv_rd_prof_fetch_spec2(rd, reset)) return -1;
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
+    if (pcamv_rd_prof_fetch_spec4(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     return 0;
 }
@@ -201,15 +209,22 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
             const char *inst = getenv("PCAMV_RD_INSTANCE");
             /* measured (1080p umh subme 7, MB/s lo / hi): 256 chains 2.31 / 2.21 M, 512: 4.43 / 4.19 M, 1024: 6.84 / 7.77 M -- with one
              * wave per SIMD the lo build has no free wave left at 1024 chains to take the RCA steps off the chains */
-            b->rd_lo = inst ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu);
-            /* ... and with few chains, the instance that hands a chain on speculatively after the 16x16 search (pcamv_rd_spec.hip:
-             * ~3 waves work on a chain then): PCAMV_FLOW_SPEC=0 / 1 overrides.  Needs pictures >= FLOW_SPEC_MIN_MBW macroblocks wide. */
+            /* Five builds (pcamv_rd*.hip).  With CABAC (raster chains) the ones that hand a chain on speculatively after the 16x16
+             * search -- ~3 waves work on a chain then --, at 1, 2 or 4 waves per SIMD by the number of chains; measured (1080p umh
+             * subme 7, M MB/s, plain / spec1 / spec2 / spec4): 256 chains 2.51 / 4.60 / - / -, 512: 4.81 / 6.77 / 8.17 / 7.90,
+             * 1024: 8.40 / 7.31 / 11.9 / 14.0, 2048: 14.3 / 7.30 / 12.5 / 18.3, 3072: 18.4 / - / - / 19.0, 4096: 19.5 / - / - / 19.3.
+             * Without a chain (CAVLC: wavefront order) and for thousands of chains the plain builds: "lo" (1 wave per SIMD) while the
+             * chains fit that anyway, else "hi" (4).  PCAMV_RD_INSTANCE=lo|hi|spec|spec2|spec4 and PCAMV_FLOW_SPEC=0|1 override.
+             * The speculative chain needs pictures >= FLOW_SPEC_MIN_MBW macroblocks wide. */
             const char *sp = getenv("PCAMV_FLOW_SPEC");
-            b->rd_spec = b->fl.raster && F.mb_w >= FLOW_SPEC_MIN_MBW && !(inst && strcmp(inst, "spec")) &&
-                         (sp ? atoi(sp) != 0 : (inst ? !strcmp(inst, "spec") : n <= PCAMV_SPEC_MAX_CHAINS));
-            if (b->rd_spec) b->rd_lo = 0;
-            b->fl.spec = b->rd_spec;
-            per_cu = b->rd_spec ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
+            const int can_spec = b->fl.raster && F.mb_w >= FLOW_SPEC_MIN_MBW;
+            int want_spec = inst ? !strncmp(inst, "spec", 4) : (sp ? atoi(sp) != 0 : n <= PCAMV_SPEC_MAX_CHAINS);
+            b->rd_spec = can_spec && want_spec ? (inst && !strcmp(inst, "spec") ? 1 : inst && !strcmp(inst, "spec2") ? 2 : inst && !strcmp(inst, "spec4") ? 4 :
+                                                   n <= PCAMV_SPEC1_MAX_CHAINS ? 1 : n <= PCAMV_SPEC2_MAX_CHAINS ? 2 : 4) : 0;
+            b->rd_lo = !b->rd_spec && (inst && strncmp(inst, "spec", 4) ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu));
+            b->fl.spec = b->rd_spec != 0;
+            per_cu = b->rd_spec == 1 ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_spec == 2 ? pcamv_flow_rd_waves_per_cu_spec2() :
+                     b->rd_spec == 4 ? pcamv_flow_rd_waves_per_cu_spec4() : b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
             if (per_cu < 0) e = hipErrorUnknown;
         }
         const char *wv = getenv("PCAMV_FLOW_WAVES");
@@ -519,7 +534,9 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
             if (F.b_mbrd) {
-                if (b->rd_spec) pcamv_launch_flow_rd_spec((unsigned)b->flow_waves, st, dF, b->fl);
+                if (b->rd_spec == 1) pcamv_launch_flow_rd_spec((unsigned)b->flow_waves, st, dF, b->fl);
+                else if (b->rd_spec == 2) pcamv_launch_flow_rd_spec2((unsigned)b->flow_waves, st, dF, b->fl);
+                else if (b->rd_spec == 4) pcamv_launch_flow_rd_spec4((unsigned)b->flow_waves, st, dF, b->fl);
                 else if (b->rd_lo) pcamv_launch_flow_rd_lo((unsigned)b->flow_waves, st, dF, b->fl);
                 else pcamv_launch_flow_rd((unsigned)b->flow_waves, st, dF, b->fl);
             }

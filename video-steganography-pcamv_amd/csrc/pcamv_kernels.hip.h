@@ -680,6 +680,10 @@ void pcamv_launch_flow_rd_lo(unsigned waves, hipStream_t st, const FrameDev *dF,
 int pcamv_flow_rd_waves_per_cu_lo(void);
 void pcamv_launch_flow_rd_spec(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu_spec(void);
+void pcamv_launch_flow_rd_spec2(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu_spec2(void);
+void pcamv_launch_flow_rd_spec4(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu_spec4(void);
 
 /* pass 2 + loop filter through the same queue: the tasks are short (~5 us), which only works because the hand-off
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the

@@ -22,11 +22,17 @@
 #ifndef PCAMV_NO_RESIDUAL_CALL
 #define PCAMV_RESIDUAL_CALL 1      /* pcamv_prims_rd_gpu.h: the CABAC residual walk as a function of its own */
 #endif
-#if defined(PCAMV_RD_SPEC)          /* pcamv_rd_spec.hip: the speculative raster chain for few GOPs in flight, one wave per SIMD */
+#if defined(PCAMV_RD_SPEC)          /* pcamv_rd_spec*.hip: the speculative raster chain, PCAMV_RD_SPEC = waves per SIMD (1, 2 or 4) */
+#if PCAMV_RD_SPEC == 1
 #define PCAMV_RD_LO 1
-#define PCAMV_RD_OCC 1
-#define PCAMV_RD_VARIANT 6
 #define RD_NAME(x) x##_spec
+#elif PCAMV_RD_SPEC == 2
+#define RD_NAME(x) x##_spec2
+#else
+#define RD_NAME(x) x##_spec4
+#endif
+#define PCAMV_RD_OCC PCAMV_RD_SPEC
+#define PCAMV_RD_VARIANT 6
 #elif defined(PCAMV_RD_LO)
 #define PCAMV_RD_OCC 1
 #define RD_NAME(x) x##_lo

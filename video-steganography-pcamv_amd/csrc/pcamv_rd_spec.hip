@@ -5,5 +5,5 @@
  * against its predecessor's final one before its RD stage.  For few GOPs in flight (the chip waits for the chains): one wave
  * per SIMD, every register, like pcamv_rd_lo.hip.
  */
-#define PCAMV_RD_SPEC 1
+#define PCAMV_RD_SPEC 1        /* waves per SIMD */
 #include "pcamv_rd.hip"
