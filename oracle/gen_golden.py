@@ -252,6 +252,11 @@ if __name__ == "__main__":
         pslice_fixture("pslice_cavlc_cif_hex_subme5_p4x4_qp10", 352, 288, "hex", 5, 10, 0x31, 22, 160, noise=40, cabac=0)
         pslice_fixture("pslice_cavlc_qcif_hex_subme6_qp34", 176, 144, "hex", 6, 34, 0x11, 9, 0, noise=30, cabac=0)
         sys.exit(0)
+    if "--rd-psub8-only" in sys.argv:          # x264_rd_cost_part: sub-8x8 partitions at --subme 6 / 7 (round 3)
+        analysis_fixture("qcif_hex_subme6_psub8", 176, 144, "hex", 6, 26, 0x30, 61, 0, noise=30)
+        analysis_fixture("qcif_hex_subme7_psub8_cavlc", 176, 144, "hex", 7, 20, 0x30, 62, 32, cabac=0, noise=40)
+        analysis_fixture("qcif_umh_subme6_psub8", 176, 144, "umh", 6, 34, 0x30, 63, 0, noise=25)
+        sys.exit(0)
     if "--rd-only" in sys.argv:
         rd_primitive_fixture()
         analysis_fixture("qcif_hex_subme6", 176, 144, "hex", 6, 26, 0x10, 5, 48)

@@ -392,7 +392,7 @@ typedef struct {
     int cbp_luma, cbp_chroma;
     uint8_t nzq[16], nnz[16];                        /* luma 4x4: quantised to non-zero; still non-zero after decimation (h->mb.non_zero_count != 0) */
     /* --subme >= 6 (pcamv_oracle_rd.inc) */
-    int mbrd, lambda2, b_fast_intra, fenc_satd_sum, fenc_sa8d_sum;
+    int mbrd, lambda2, b_fast_intra, fenc_satd_sum, fenc_sa8d_sum, fenc_satd[4][4], fenc_sa8d[2][2];
     int16_t lv[24][16], lvdc[2][4];                  /* h->dct.luma4x4 (zigzag levels; 16..23 chroma with [0] = 0), h->dct.chroma_dc */
     uint8_t nzc[48];                                 /* h->mb.cache.non_zero_count, 0x80 = unavailable */
     int16_t cmvd[48][2];                             /* h->mb.cache.mvd */
@@ -583,7 +583,20 @@ static void mb_load(orc_t *o, mbc_t *m, int mb_x, int mb_y, int qp)
     static const uint8_t bottom[8] = {10, 11, 14, 15, 18, 19, 22, 23}, right[8] = {5, 7, 13, 15, 17, 19, 21, 23};
     static const uint8_t top_pos[8] = {4 + 0 * 8, 5 + 0 * 8, 6 + 0 * 8, 7 + 0 * 8, 1 + 0 * 8, 2 + 0 * 8, 1 + 3 * 8, 2 + 3 * 8};
     static const uint8_t left_pos[8] = {3 + 1 * 8, 3 + 2 * 8, 3 + 3 * 8, 3 + 4 * 8, 0 + 1 * 8, 0 + 2 * 8, 0 + 4 * 8, 0 + 5 * 8};
-    memset(m->nzc, 0, sizeof(m->nzc)); memset(m->cmvd, 0, sizeof(m->cmvd)); memset(m->i4mode, -1, sizeof(m->i4mode));
+    /* h->mb.cache is ONE structure for the whole encoder: x264_macroblock_cache_load fills the neighbours' entries and leaves the
+     * current macroblock's own non_zero_count / mvd entries as the macroblock coded before it left them.  Nearly everything writes
+     * them before reading them; the sub-partition RD trials (x264_rd_cost_part, below) do read them ("the NNZ values used for
+     * context selection for future blocks are those left over from previous RDO calls", analyse.c:2158).  mbc_t is one structure
+     * for the whole frame too: the inner entries stay, the rest is reset (a frame starts from zeros: what the previous frame's
+     * second pass would have left is outside this path). */
+    { uint8_t keep_nz[24]; int16_t keep_mvd[16][2];
+      for (int i = 0; i < 24; i++) keep_nz[i] = m->nzc[scan8_all[i]];
+      for (int i = 0; i < 16; i++) { keep_mvd[i][0] = m->cmvd[scan8(i)][0]; keep_mvd[i][1] = m->cmvd[scan8(i)][1]; }
+      memset(m->nzc, 0, sizeof(m->nzc)); memset(m->cmvd, 0, sizeof(m->cmvd)); memset(m->i4mode, -1, sizeof(m->i4mode));
+      if (o->p.inter & PCAMV_ANALYSE_PSUB8x8) {
+          for (int i = 0; i < 24; i++) m->nzc[scan8_all[i]] = keep_nz[i];
+          for (int i = 0; i < 16; i++) { m->cmvd[scan8(i)][0] = keep_mvd[i][0]; m->cmvd[scan8(i)][1] = keep_mvd[i][1]; }
+      } }
     for (int i = 0; i < 8; i++) {
         m->nzc[top_pos[i]] = (m->neighbour & NB_TOP) ? o->nnz[top][bottom[i]] : 0x80;
         m->nzc[left_pos[i]] = (m->neighbour & NB_LEFT) ? o->nnz[m->mb_xy - 1][right[i]] : 0x80;
@@ -1526,6 +1539,7 @@ static void analyse_mb(mbc_t *m, int embed, pcamv_mb_t *out)
     ana_t A, *a = &A;
     memset(a, 0, sizeof(*a));
     a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = COST_MAX;       /* analyse.c:321-332 */
+    for (int i = 0; i < 4; i++) a->cost4x4[i] = a->cost8x4[i] = a->cost4x8[i] = COST_MAX;
     int b_skip = 0, b_try_pskip = 0, i_cost;
     unsigned flags = o->p.inter;
     memset(out, 0, sizeof(*out));
@@ -1663,7 +1677,6 @@ int orc_analyse_pframe(orc_t *o, int qp, int embed, pcamv_mb_t *out_mb, uint8_t 
     memset(m, 0, sizeof(*m));
     memset(o->mb_type, PCAMV_P_SKIP, o->n_mb);
     if (o->p.i_subpel_refine >= 6) {
-        if ((o->p.inter & PCAMV_ANALYSE_PSUB8x8)) { free(m); return -5; }      /* sub-8x8 RD (x264_rd_cost_part) not restated */
         orc_cabac_init_p(o->cabac_state, qp);                                 /* x264_cabac_context_init at the slice start, encoder.c:1227 */
     }
     for (int my = 0; my < o->mb_h; my++)

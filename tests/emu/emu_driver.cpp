@@ -6,6 +6,7 @@
  */
 #define PCAMV_HOST_EMU 1
 #include <stdlib.h>
+#include <stdio.h>
 #include "pcamv_common.h"
 #include "pcamv_prims_emu.h"
 #include "pcamv_mbkernels.h"
@@ -37,7 +38,7 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     /* --subme >= 6 */
     F.ref_is_inter = prev_mv != NULL;
     F.nb_nz = (uint8_t *)calloc((size_t)F.n_mb, 16); F.nb_cbp = (int16_t *)calloc((size_t)F.n_mb, 2); F.nb_mvd = (int16_t *)calloc((size_t)F.n_mb * 16, 2);
-    uint8_t cab[464], cab_init[464]; uint32_t cab_tab[256];
+    uint8_t cab[PCAMV_CHAIN_BYTES] = {0}, cab_init[PCAMV_CHAIN_BYTES] = {0}; uint32_t cab_tab[256];
     pcamv_build_cabac_init(qp, cab_init); pcamv_build_cabac_tab(cab_tab);
     F.cabac = cab; F.cabac_init = cab_init; F.cabac_tab = cab_tab; F.dbg_hash = dbg_hash;
     int16_t *cost = (int16_t *)malloc(PCAMV_COST_MV_LEN * sizeof(int16_t));
@@ -46,21 +47,21 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     MBLocal *L = (MBLocal *)malloc(sizeof(MBLocal));
     Analysis *a = (Analysis *)malloc(sizeof(Analysis));
     if (diag_order == 3) {  /* raster order, fused: what the dataflow schedule does when the entropy coder is CABAC (one chain per frame) */
-        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) { mbk_search<3>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); }
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) { mbk_search<11>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux); free(F.nb_nz); free(F.nb_cbp); free(F.nb_mvd);
         return 0;
     }
     if (diag_order == 2) {  /* dataflow schedule: search, then RCA + reconstruction of the same macroblock, in a dependency-legal order */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<3>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); } }
+            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<11>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); } }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
         return 0;
     }
     if (diag_order) {       /* the order the GPU uses: anti-diagonals x + 2y = d */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search<3>(F, L, a, x, y); }
+            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search<11>(F, L, a, x, y); }
     } else
-        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) mbk_search<3>(F, L, a, x, y);
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) mbk_search<11>(F, L, a, x, y);
     if (embed)
         for (int xy = F.n_mb - 1; xy >= 0; xy--) for (int k = 15; k >= 0; k--) mbk_rca(F, L, a, xy, k);
     for (int xy = 0; xy < F.n_mb; xy++) mbk_encode(F, L, a, xy);

@@ -394,6 +394,11 @@ static inline void prim_rd_load(const FrameDev &F, MBLocal *L)
     static const uint8_t top_pos[8] = {4, 5, 6, 7, 1, 2, 1 + 3 * 8, 2 + 3 * 8}, left_pos[8] = {3 + 8, 3 + 16, 3 + 24, 3 + 32, 0 + 8, 0 + 16, 0 + 32, 0 + 40};
     const int xy = L->mb_xy, top = xy - F.mb_w;
     memset(L->nzc, 0, sizeof(L->nzc)); memset(L->cmvd, 0, sizeof(L->cmvd)); memset(L->i4mode, -1, sizeof(L->i4mode));
+    if (F.inter & PCAMV_ANALYSE_PSUB8x8) {       /* the macroblock's own entries as the macroblock coded before it left them (PCAMV_CHAIN_*) */
+        const uint8_t *src = xy == 0 ? F.cabac_init : F.cabac;
+        for (int b = 0; b < 24; b++) L->nzc[scan8_all_of(b)] = src[PCAMV_CHAIN_NZ + b];
+        for (int b = 0; b < 16; b++) memcpy(L->cmvd[scan8_of(b)], src + PCAMV_CHAIN_MVD + 4 * b, 4);
+    }
     for (int k = 0; k < 8; k++) {
         L->nzc[top_pos[k]] = (L->neighbour & NB_TOP) ? F.nb_nz[top * 16 + k] : 0x80;
         L->nzc[left_pos[k]] = (L->neighbour & NB_LEFT) ? F.nb_nz[(xy - 1) * 16 + 8 + k] : 0x80;
@@ -535,6 +540,7 @@ static inline void prim_intra4_encode(const FrameDev &F, MBLocal *L, int idx, in
     }
     uint8_t tmp[4 * 16];
     for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) tmp[y * 16 + x] = p[y * 4 + x];
+    L->nzc[scan8_of(idx)] = (uint8_t)(nz != 0);         /* encoder/macroblock.c:135: stays in the cache */
     if (nz) {
         int qbits = F.qp / 6 - 4;
         for (int i = 0; i < 16; i++) {
@@ -738,6 +744,150 @@ static inline int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
     }
     return bits;
 }
+/* ---- x264_rd_cost_part for one 8x8 of a P_8x8 macroblock (pcamv_logic.h rd_cost_part8) ---- */
+/* x264_macroblock_encode_p8x8 (encoder/macroblock.c:929-1052): prediction with the sub-partition's MVs, the 8x8's four luma blocks
+ * with their own decimation rule, its two chroma 4x4 blocks without DC; levels, non-zero flags and reconstruction stay */
+static inline void prim_encode_p8x8(const FrameDev &F, MBLocal *L, int i8)
+{
+    prim_predict_mb(F, L, 0);                   /* (the whole macroblock: only this 8x8's pixels are looked at) */
+    int dec8 = 0, nnz8x8 = 0, blk_nz[4];
+    int16_t deq[6][16];
+    for (int k = 0; k < 6; k++) {
+        const int is_l = k < 4, b = is_l ? 4 * i8 + k : 16 + i8 + (k - 4) * 4;
+        const int px = is_l ? 4 * blk_x_of(b) : (k - 4) * 8 + (i8 & 1) * 4, py = is_l ? 4 * blk_y_of(b) : 16 + (i8 >> 1) * 4;
+        int d[4][4], t[4][4], c[16];
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y][x] = L->fenc[(py + y) * 16 + px + x] - L->pred[(py + y) * 16 + px + x];
+        for (int i = 0; i < 4; i++) {
+            int s03 = d[i][0] + d[i][3], s12 = d[i][1] + d[i][2], d03 = d[i][0] - d[i][3], d12 = d[i][1] - d[i][2];
+            t[0][i] = s03 + s12; t[1][i] = 2 * d03 + d12; t[2][i] = s03 - s12; t[3][i] = d03 - 2 * d12;
+        }
+        for (int i = 0; i < 4; i++) {
+            int s03 = t[i][0] + t[i][3], s12 = t[i][1] + t[i][2], d03 = t[i][0] - t[i][3], d12 = t[i][1] - t[i][2];
+            c[i * 4] = s03 + s12; c[i * 4 + 1] = 2 * d03 + d12; c[i * 4 + 2] = s03 - s12; c[i * 4 + 3] = d03 - 2 * d12;
+        }
+        if (!is_l) c[0] = 0;
+        int nz = 0;
+        for (int i = 0; i < 16; i++) {
+            int cls = (i & 1) + ((i >> 2) & 1), mf = F.q_mf[is_l ? 0 : 1][cls], bias = F.q_bias[is_l ? 0 : 1][cls], v = c[i];
+            c[i] = v > 0 ? ((bias + v) * mf >> 16) : -((bias - v) * mf >> 16);
+            nz |= c[i];
+        }
+        nz = nz != 0;
+        L->nzc[scan8_all_of(b)] = (uint8_t)nz;
+        if (is_l) blk_nz[k] = nz;
+        if (nz) {
+            int16_t lv[16];
+            for (int q = 0; q < 16; q++) L->coef[b][q] = lv[q] = (int16_t)c[zz4_tab[q]];
+            if (is_l) {
+                nnz8x8 = 1;
+                if (F.b_dct_decimate) {         /* x264_decimate_score16 */
+                    int idx = 15, score = 0;
+                    while (idx >= 0 && lv[idx] == 0) idx--;
+                    while (idx >= 0) {
+                        if ((unsigned)(lv[idx--] + 1) > 2) { score = 9; break; }
+                        int run = 0;
+                        while (idx >= 0 && lv[idx] == 0) { idx--; run++; }
+                        score += decimate_tab4[run];
+                    }
+                    dec8 += score;
+                }
+            }
+            const int qp = is_l ? F.qp : F.chroma_qp, qbits = qp / 6 - 4;
+            for (int i = 0; i < 16; i++) {
+                int cls = (i & 1) + ((i >> 2) & 1), dq = is_l ? F.dq_mf[cls] : F.dq_mf_c[cls];
+                deq[k][i] = qbits >= 0 ? (int16_t)((c[i] * dq) << qbits) : (int16_t)((c[i] * dq + (1 << (-qbits - 1))) >> (-qbits));
+            }
+            if (!is_l) emu_idct_add(L->pred + py * 16 + px, deq[k]);
+        }
+    }
+    if (F.b_dct_decimate && dec8 < 4) nnz8x8 = 0;
+    for (int k = 0; k < 4; k++) {
+        const int b = 4 * i8 + k;
+        if (nnz8x8) { if (blk_nz[k]) emu_idct_add(L->pred + 4 * blk_y_of(b) * 16 + 4 * blk_x_of(b), deq[k]); }
+        else L->nzc[scan8_of(b)] = 0;            /* STORE_8x8_NNZ( i8, 0 ) */
+    }
+    L->cbp_luma = (L->cbp_luma & ~(1 << i8)) | nnz8x8 << i8;
+    L->cbp_chroma = 2;
+}
+/* ssd_plane( PIXEL_8x8, luma ) + ssd_plane( PIXEL_4x4, U / V ) of that 8x8 (rdo.c:106-128) */
+static inline int prim_ssd_part8(const FrameDev &F, MBLocal *L, int i8)
+{
+    const int x8 = (i8 & 1) * 8, y8 = (i8 >> 1) * 8;
+    int ssd = 0;
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { int d = L->fenc[(y8 + y) * 16 + x8 + x] - L->pred[(y8 + y) * 16 + x8 + x]; ssd += d * d; }
+    for (int ch = 0; ch < 2; ch++)
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+            const int o = (16 + y8 / 2 + y) * 16 + ch * 8 + x8 / 2 + x, d = L->fenc[o] - L->pred[o];
+            ssd += d * d;
+        }
+    if (F.psy_rd) {
+        int s4[16], dc4[16], s8[4], f4[16], fdc4[16], f8[4];
+        emu_had_sums(L->pred, 16, s4, dc4, s8);
+        emu_had_sums(L->fenc, 16, f4, fdc4, f8);
+        const int r = 4 * (i8 >> 1) * 2 + 2 * (i8 & 1);      /* first 4x4 (raster) of the 8x8 */
+        const int rr[4] = {r, r + 1, r + 4, r + 5};
+        int sum4 = 0, dc = 0, fsatd = 0, fdc = 0;
+        for (int k = 0; k < 4; k++) { sum4 += s4[rr[k]]; dc += dc4[rr[k]]; fsatd += (f4[rr[k]] >> 1) - (fdc4[rr[k]] >> 1); fdc += fdc4[rr[k]]; }
+        const int fsa8d = ((f8[i8] + 2) >> 2) - (fdc >> 2);
+        const int satd = (iabs(((sum4 - dc) >> 1) - fsatd) + iabs(((s8[i8] - dc) >> 2) - fsa8d)) >> 1;
+        ssd += (satd * F.psy_rd * F.lambda + 128) >> 8;
+    }
+    return ssd;
+}
+/* the residual part of x264_partition_size_cabac (encoder/cabac.c:1058-1074) for the 8x8: its four luma blocks when the 8x8 is
+ * coded, then its two chroma AC blocks (their coded_block_flags are always written) */
+static inline void emu_cab_block(MBLocal *L, CabWalk &C, int cat, int idx, const int16_t *l, int count)
+{
+    static const uint16_t sig_off[5] = {105, 120, 134, 149, 152}, last_off[5] = {166, 181, 195, 210, 213}, lvl_off[5] = {227, 237, 247, 257, 266};
+    static const uint8_t lvl1[8] = {1, 2, 3, 4, 0, 0, 0, 0}, lvlgt1[8] = {5, 5, 5, 5, 6, 7, 8, 9}, nxt[2][8] = {{1, 2, 3, 3, 4, 5, 6, 7}, {4, 4, 4, 4, 5, 6, 7, 7}};
+    const int a = L->nzc[scan8_all_of(idx) - 1] & 0x7f, b = L->nzc[scan8_all_of(idx) - 8] & 0x7f;
+    const int inc = 4 * cat + 2 * !!b + !!a, flag = L->nzc[scan8_all_of(idx)] != 0;
+    prim_cb_dec(L, C, 85 + inc, flag);
+    if (!flag) return;
+    int last = count - 1;
+    while (last >= 0 && !l[last]) last--;
+    for (int i = 0; i < imin(last + 1, count - 1); i++) {
+        prim_cb_dec(L, C, sig_off[cat] + i, l[i] != 0);
+        if (l[i]) prim_cb_dec(L, C, last_off[cat] + i, i == last);
+    }
+    int node = 0;
+    for (int i = last; i >= 0; i--) {
+        if (!l[i]) continue;
+        const int am1 = iabs(l[i]) - 1, prefix = imin(am1, 14);
+        if (prefix) {
+            prim_cb_dec(L, C, lvl_off[cat] + lvl1[node], 1);
+            for (int q = 0; q < prefix - 1; q++) prim_cb_dec(L, C, lvl_off[cat] + lvlgt1[node], 1);
+            if (prefix < 14) prim_cb_dec(L, C, lvl_off[cat] + lvlgt1[node], 0); else C.bits += size_ue_of((unsigned)(am1 - 14)) << 8;
+            node = nxt[1][node];
+        } else { prim_cb_dec(L, C, lvl_off[cat] + lvl1[node], 0); node = nxt[0][node]; }
+        C.bits += 256;
+    }
+}
+static inline void prim_cab_residual_part(const FrameDev &F, MBLocal *L, CabWalk &C, int i8)
+{
+    (void)F;
+    if (L->cbp_luma & (1 << i8)) for (int k = 0; k < 4; k++) emu_cab_block(L, C, 2, 4 * i8 + k, L->coef[4 * i8 + k], 16);
+    emu_cab_block(L, C, 4, 16 + i8, L->coef[16 + i8] + 1, 15);
+    emu_cab_block(L, C, 4, 20 + i8, L->coef[20 + i8] + 1, 15);
+}
+/* x264_partition_size_cavlc for the 8x8 (encoder/cavlc.c:621-661): the sub-partition's MV differences, its luma blocks when coded,
+ * its two chroma AC blocks; leaves the coefficient counts in L->nzc */
+static inline int prim_cavlc_part8(const FrameDev &F, MBLocal *L, int i8)
+{
+    int bits = 0, mvp[2];
+    (void)F;
+#define EMVD(idx, w) (predict_mv(L, idx, w, mvp), emu_size_se(L->cmv[scan8_of(idx)][0] - mvp[0]) + emu_size_se(L->cmv[scan8_of(idx)][1] - mvp[1]))
+    switch (L->sub_part[i8]) {
+    case PCAMV_D_L0_8x8: bits += EMVD(4 * i8, 2); break;
+    case PCAMV_D_L0_8x4: bits += EMVD(4 * i8, 2); bits += EMVD(4 * i8 + 2, 2); break;
+    case PCAMV_D_L0_4x8: bits += EMVD(4 * i8, 1); bits += EMVD(4 * i8 + 1, 1); break;
+    default: for (int k = 0; k < 4; k++) bits += EMVD(4 * i8 + k, 1); break;
+    }
+#undef EMVD
+    if (L->cbp_luma & (1 << i8)) for (int k = 0; k < 4; k++) bits += emu_cavlc_block(L, 4 * i8 + k, L->coef[4 * i8 + k], 16);
+    bits += emu_cavlc_block(L, 16 + i8, L->coef[16 + i8] + 1, 15) + emu_cavlc_block(L, 20 + i8, L->coef[20 + i8] + 1, 15);
+    return bits;
+}
 static inline void prim_rd_commit(const FrameDev &F, MBLocal *L, int skip)
 {
     static const uint8_t bottom[8] = {10, 11, 14, 15, 18, 19, 22, 23}, right[8] = {5, 7, 13, 15, 17, 19, 21, 23};
@@ -755,6 +905,10 @@ static inline void prim_rd_commit(const FrameDev &F, MBLocal *L, int skip)
     if (F.b_cabac) {
         memcpy(F.cabac, L_CAB(L, 0), 464);
         if (F.dbg_hash) { uint32_t h = 2166136261u; for (int i = 0; i < 460; i++) h = (h ^ L_CAB(L, 0)[i]) * 16777619u; F.dbg_hash[xy] = h; }
+    }
+    if (F.inter & PCAMV_ANALYSE_PSUB8x8) {
+        for (int b = 0; b < 24; b++) F.cabac[PCAMV_CHAIN_NZ + b] = skip ? 0 : L->nzc[scan8_all_of(b)];
+        for (int b = 0; b < 16; b++) memcpy(F.cabac + PCAMV_CHAIN_MVD + 4 * b, L->cmvd[scan8_of(b)], 4);
     }
 }
 static inline int prim_chroma_ssd(const FrameDev &F, MBLocal *L, int ch)

@@ -227,21 +227,27 @@ RD_SWEEP = [
     (352, 288, "hex", 6, 28, 56, 64, 0, 1.0, 12, 1),
     (320, 240, "umh", 7, 26, 57, 96, 1, 1.0, 6, 1),        # config 3's options (--me umh --subme 7) on a wider picture
     (1280, 720, "hex", 6, 26, 11, 320, 1, 1.0, 6, 1),      # 720p: the raster chain over 3600 macroblocks
+    # sub-8x8 partitions priced by x264_rd_cost_part (rdo.c:202-245; a 12th field: the inter flags)
+    (176, 144, "hex", 6, 26, 61, 0, 1, 1.0, 30, 1, 0x30),
+    (176, 144, "umh", 7, 18, 68, 32, 0, 1.0, 40, 1, 0x30),   # CAVLC: non-zero COUNTS left over between the trials
+    (320, 240, "dia", 6, 32, 69, 64, 1, 0.5, 25, 1, 0x30),
+    (64, 48, "hex", 6, 24, 70, 0, 1, 1.0, 35, 1, 0x30),      # 4 macroblocks wide: too narrow for the speculative chain (plain one-wave-per-SIMD build)
 ]
 
 
-@pytest.mark.parametrize("cfg", RD_SWEEP, ids=[f"{c[0]}x{c[1]}_{c[2]}_s{c[3]}_qp{c[4]}_{'cabac' if c[7] else 'cavlc'}_psy{c[8]}_e{c[10]}" for c in RD_SWEEP])
+@pytest.mark.parametrize("cfg", RD_SWEEP, ids=[f"{c[0]}x{c[1]}_{c[2]}_s{c[3]}_qp{c[4]}_{'cabac' if c[7] else 'cavlc'}_psy{c[8]}_e{c[10]}{'_p4x4' if len(c) > 11 else ''}" for c in RD_SWEEP])
 def test_rd_mode_decision_matches_oracle(pc, cfg):
     """--subme 6 / 7 (the reference's default): intra SATD thresholds, psy-RD, size-only CABAC / CAVLC, context adaptation --
     record, reconstruction and (CABAC) the context states after every macroblock against the oracle (pinned on the reference's
     code by tests/golden/*subme6* / *subme7* and tests/test_oracle_vs_ref_live.py); two chained P frames"""
     import orc
     from pcamv_amd.synth import make_clip
-    W, H, me, subme, qp, seed, static, cabac, psy, noise, embed = cfg
+    W, H, me, subme, qp, seed, static, cabac, psy, noise, embed = cfg[:11]
+    inter = cfg[11] if len(cfg) > 11 else 0x10
     clip = make_clip(W, H, 3, seed=seed, static_cols=static, noise=noise)
     mvr = pc.level_mv_range(W, H)
-    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=0x11, cabac=cabac, psy_rd=psy)
-    p = _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr, cabac=cabac, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset)
+    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter | 1, cabac=cabac, psy_rd=psy)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr, cabac=cabac, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset)
     enc = pc.Encoder(p)
     o = orc.Oracle(op)
     ho = o.debug_state_hash()
@@ -356,10 +362,7 @@ def test_open_rejects_unsupported(pc):
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)
     p = pc.param_default(176, 144)
-    pc.param_parse(p, "partitions", "i4x4,p8x8,p4x4")     # subme 6 (the default) with sub-8x8 partitions: x264_rd_cost_part is not built
-    with pytest.raises(pc.PcamvError):
-        pc.Encoder(p)
-    pc.param_parse(p, "subme", 5)            # ... fine without the RD stage
+    pc.param_parse(p, "partitions", "all")   # subme 6 (the default) with sub-8x8 partitions: x264_rd_cost_part, built in round 3
     pc.Encoder(p).close()
     p = pc.param_default(176, 144)
     pc.param_parse(p, "me", "tesa")          # the default subme 6 with --me tesa: not built
@@ -592,7 +595,7 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     enc.close(); o.close(); o2.close()
 
 
-def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate=0.5, statics=(0, 64, 128), noise=6, hashes=False):
+def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate=0.5, statics=(0, 64, 128), noise=6, hashes=False, inter=0x10):
     """GOPs advanced together through closed-loop steps (dataflow analysis, embedding, then pass 2 + loop filter through the same
     dataflow queue; every later step's reference is the step's own deblocked picture and final motion field, both taken from the
     device): records, embedding vectors, deblocked pictures vs the oracle, and the payload back out of the final motion vectors
@@ -605,9 +608,9 @@ def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate
     d = [[[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip] for clip in clips]
     mvr = pc.level_mv_range(W, H)
     rd = subme >= 6
-    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=0x11 if rd else 0x10)
-    p = _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset) if rd \
-        else _params(pc, W, H, pc.ME_NAMES[me], subme, 0x10, mvr)
+    op = orc.make_params(W, H, me=me, subme=subme, mv_range=mvr, inter=inter | 1 if rd else inter)
+    p = _params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr, psy_fix8=op.i_psy_rd, chroma_qp_offset=op.i_chroma_qp_offset) if rd \
+        else _params(pc, W, H, pc.ME_NAMES[me], subme, inter, mvr)
     encs = [pc.Encoder(p) for _ in range(n_gops)]
     batch = pc.Batch(encs)
     batch.set_closed_loop(True)

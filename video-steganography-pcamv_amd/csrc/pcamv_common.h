@@ -91,8 +91,10 @@ struct FrameDev {
     uint8_t *nb_nz;                /* [n_mb][16] non-zero flags (CABAC) / coefficient counts (CAVLC): 0..7 bottom row (4 luma, 2 Cb, 2 Cr), 8..15 right column */
     int16_t *nb_cbp;               /* [n_mb] h->mb.cbp: luma | chroma << 4 | chroma DC coded bits << 9 */
     int16_t *nb_mvd;               /* [n_mb][8][2] MV differences of the bottom row (0..3) and right column (4..7) of 4x4 blocks */
-    uint8_t *cabac;                /* [464] context states after the macroblock coded last (460 used) */
-    const uint8_t *cabac_init;     /* [464] states at the slice start for this QP (H.264 9.3.1.1, cabac_init_idc 0) */
+    uint8_t *cabac;                /* [PCAMV_CHAIN_BYTES] what the macroblock coded last hands to the next one in coding order: the context
+                                    * states [0, 464) (460 used) and, with sub-8x8 partitions, its own non-zero flags / counts and MV
+                                    * differences (x264's cache keeps them and x264_rd_cost_part reads them: PCAMV_CHAIN_NZ / _MVD) */
+    const uint8_t *cabac_init;     /* [PCAMV_CHAIN_BYTES] the same at the slice start: states for this QP (H.264 9.3.1.1, cabac_init_idc 0), zeros */
     const uint32_t *cabac_tab;     /* [256] per (state, bin): 8.8 fixed-point bits << 8 | next state */
     uint32_t *dbg_hash;            /* diagnostics: [n_mb] FNV-1a of the context states after each macroblock, or NULL */
 };
@@ -182,6 +184,9 @@ struct MBLocal {
  * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA
  * reconstruction buffers hold the intra 4x4 analysis' picture (17 rows of 32: row -1 and column -1 are the neighbours);
  * the P_SKIP probe's coefficient scratch (coef / cdc) holds a trial's quantised levels in scan order. */
+#define PCAMV_CHAIN_NZ 464          /* 24 bytes: non_zero_count of blocks 0..23 */
+#define PCAMV_CHAIN_MVD 488         /* 16 x 4 bytes: mvd of the luma blocks 0..15 (x264 block order) */
+#define PCAMV_CHAIN_BYTES 576
 #define L_CAB(L, k) ((uint8_t *)(L)->win + 464 * (k))      /* k = 0: the slice's states as the macroblock coded last left them */
 #define PCAMV_CAB_USED 276                                  /* contexts 0..275 are all a P slice of this path touches (coeff_abs_level_minus1 ends at 275) */
 #define L_CABT(L) ((uint8_t *)(L)->win + 464)               /* states at the end of the running size trial */

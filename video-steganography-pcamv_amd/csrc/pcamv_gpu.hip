@@ -200,7 +200,9 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         }
         b->fl.total = (unsigned)total; b->fl.spin_limit = 4u << 20;
         b->fl.n_gop = n; b->fl.n_mb = F.n_mb; b->fl.mb_w = F.mb_w; b->fl.mb_h = F.mb_h; b->fl.fused = 1; b->fl.unit = 1;
-        b->fl.raster = F.b_mbrd && F.b_cabac;
+        /* one chain per frame: the context states (CABAC), or -- sub-8x8 partitions priced by x264_rd_cost_part -- the non-zero counts
+         * / MV differences the macroblock coded before this one leaves in the cache (PCAMV_CHAIN_NZ) */
+        b->fl.raster = F.b_mbrd && (F.b_cabac || (ctxs[0]->p.inter & PCAMV_ANALYSE_PSUB8x8));
         int per_cu = 0, n_cu = 0;
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_analyse_flow, 64, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, b->device);
@@ -222,6 +224,8 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
             b->rd_spec = can_spec && want_spec ? (inst && !strcmp(inst, "spec") ? 1 : inst && !strcmp(inst, "spec2") ? 2 : inst && !strcmp(inst, "spec4") ? 4 :
                                                    n <= PCAMV_SPEC1_MAX_CHAINS ? 1 : n <= PCAMV_SPEC2_MAX_CHAINS ? 2 : 4) : 0;
             b->rd_lo = !b->rd_spec && (inst && strncmp(inst, "spec", 4) ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu));
+            /* sub-8x8 partitions at this level (x264_rd_cost_part): compiled into the two one-wave-per-SIMD builds only */
+            if (ctxs[0]->p.inter & PCAMV_ANALYSE_PSUB8x8) { if (b->rd_spec) b->rd_spec = 1; else b->rd_lo = 1; }
             b->fl.spec = b->rd_spec != 0;
             per_cu = b->rd_spec == 1 ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_spec == 2 ? pcamv_flow_rd_waves_per_cu_spec2() :
                      b->rd_spec == 4 ? pcamv_flow_rd_waves_per_cu_spec4() : b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
@@ -312,9 +316,8 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     *out = NULL;
     if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
     if (p->i_subpel_refine < 1 || p->i_subpel_refine > 7) return PCAMV_EUNSUP;   /* 8, 9: RD refinement of the MVs (disabled in the fork's P frames anyway, analyse.c:3112) */
-    /* RD mode decision (6, 7): not with sub-8x8 partitions (x264_rd_cost_part not built) nor with --me tesa (its survivor
-     * list and the context states want the same LDS) */
-    if (p->i_subpel_refine >= 6 && ((p->inter & PCAMV_ANALYSE_PSUB8x8) || p->i_me_method == PCAMV_ME_TESA)) return PCAMV_EUNSUP;
+    /* RD mode decision (6, 7): not with --me tesa (its survivor list and the context states want the same LDS) */
+    if (p->i_subpel_refine >= 6 && p->i_me_method == PCAMV_ME_TESA) return PCAMV_EUNSUP;
     if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_TESA) return PCAMV_EUNSUP;
     if (p->i_me_method == PCAMV_ME_TESA && p->i_me_range > TESA_MAX_RANGE) return PCAMV_EUNSUP;      /* the survivor list lives in LDS: 32 x 33 positions */
     if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
@@ -366,9 +369,9 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     HIPCHK(c, hipMemset(c->d_hdr, 0, 8 * sizeof(int)));
     if (F.b_mbrd) {
         HIPCHK(c, dalloc(&c->d_nb_nz, (size_t)F.n_mb * 16)); HIPCHK(c, dalloc(&c->d_nb_cbp, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_nb_mvd, (size_t)F.n_mb * 16));
-        HIPCHK(c, dalloc(&c->d_cabac, 464)); HIPCHK(c, dalloc(&c->d_cabac_tab, 256));
+        HIPCHK(c, dalloc(&c->d_cabac, PCAMV_CHAIN_BYTES)); HIPCHK(c, dalloc(&c->d_cabac_tab, 256));
         HIPCHK(c, hipMemset(c->d_nb_nz, 0, (size_t)F.n_mb * 16)); HIPCHK(c, hipMemset(c->d_nb_cbp, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_nb_mvd, 0, (size_t)F.n_mb * 32));
-        HIPCHK(c, hipMemset(c->d_cabac, 0, 464));
+        HIPCHK(c, hipMemset(c->d_cabac, 0, PCAMV_CHAIN_BYTES));
         uint32_t tab[256]; pcamv_build_cabac_tab(tab);
         HIPCHK(c, hipMemcpy(c->d_cabac_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
         F.nb_nz = c->d_nb_nz; F.nb_cbp = c->d_nb_cbp; F.nb_mvd = c->d_nb_mvd; F.cabac = c->d_cabac; F.cabac_tab = c->d_cabac_tab;
@@ -433,10 +436,10 @@ static int ensure_qp(pcamv_ctx *c, int qp)
     c->F.cost_mv = c->d_cost_mv[qp] + PCAMV_COST_MV_CENTRE;
     if (c->F.b_mbrd) {          /* context states at the slice start for this QP (x264_cabac_context_init, encoder.c:1227) */
         if (!c->d_cabac_init[qp]) {
-            uint8_t init[464];
+            uint8_t init[PCAMV_CHAIN_BYTES] = {0};       /* states, then nothing left over from an earlier macroblock */
             pcamv_build_cabac_init(qp, init);
-            hipError_t e = dalloc(&c->d_cabac_init[qp], (size_t)464);
-            if (e == hipSuccess) e = hipMemcpy(c->d_cabac_init[qp], init, 464, hipMemcpyHostToDevice);
+            hipError_t e = dalloc(&c->d_cabac_init[qp], (size_t)PCAMV_CHAIN_BYTES);
+            if (e == hipSuccess) e = hipMemcpy(c->d_cabac_init[qp], init, PCAMV_CHAIN_BYTES, hipMemcpyHostToDevice);
             if (e != hipSuccess) return fail(c, PCAMV_EHIP, "context initialisation upload: %s", hipGetErrorString(e));
         }
         c->F.cabac_init = c->d_cabac_init[qp];

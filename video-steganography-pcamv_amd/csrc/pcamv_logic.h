@@ -224,6 +224,9 @@ PCAMV_DEV EvalRes eval_cands(const FrameDev &F, MBLocal *L, MEState *me, const u
  * --subme >= 6 compiled in (a kernel of its own as well: its code would otherwise cost the search kernel registers). */
 #define FPEL_SATD ((TESA & 1) && F.me_method == PCAMV_ME_TESA && F.subme > 1)
 #define MBRD_ON ((TESA & 2) && F.b_mbrd)
+/* bit 3: the instance that prices sub-8x8 partitions with x264_rd_cost_part (a build of its own: compiled into the others its code costs
+ * them registers -- 22 spilled VGPRs and 135 more parked scalars in the 4-waves-per-SIMD build) */
+#define RD_PSUB_ON ((TESA & 8) && (F.inter & PCAMV_ANALYSE_PSUB8x8))
 #define FPEL_LIST (FPEL_SATD ? EV_SATD : EV_FPEL)
 #define FPEL_SAD (FPEL_SATD ? EV_SATD : 0)
 /* the n listed full-pel candidates folded into the running best, in list order (strict <) */
@@ -817,6 +820,33 @@ PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
         bits = (int)((unsigned)prim_cavlc_mb(F, L) * (unsigned)F.lambda2 + 128u) >> 8;       /* int arithmetic in the reference */
     return ssd + bits;
 }
+/* x264_rd_cost_part for one 8x8 of a P_8x8 macroblock (rdo.c:202-245, i_pixel = PIXEL_8x8): x264_macroblock_encode_p8x8 of that
+ * 8x8 with the sub-partition the cache describes (encoder/macroblock.c:929-1052), SSD + psy of its luma 8x8 and plain SSD of its two
+ * chroma 4x4, x264_partition_size_cabac / _cavlc (encoder/cabac.c:1032-1075, cavlc.c:621-661: the sub-partition's MV differences,
+ * the luma blocks when coded, always the two chroma AC blocks); (ssd << 8) + bits at 8 more bits of precision */
+PCAMV_DEV unsigned long long rd_cost_part8(const FrameDev &F, MBLocal *L, int i8)
+{
+    L->b_skip_mc = 0;
+    L->cbp_luma = 0;
+    prim_encode_p8x8(F, L, i8);
+    const unsigned long long ssd = (unsigned long long)(unsigned)prim_ssd_part8(F, L, i8);
+    unsigned long long bits;
+    if (F.b_cabac) {
+        CabWalk C;
+        prim_cab_begin(L, C, 1);
+        switch (L->sub_part[i8]) {           /* x264_cabac_mb8x8_mvd */
+        case PCAMV_D_L0_8x8: cb_mvd(L, C, 4 * i8, 2, 2); break;
+        case PCAMV_D_L0_8x4: cb_mvd(L, C, 4 * i8, 2, 1); cb_mvd(L, C, 4 * i8 + 2, 2, 1); break;
+        case PCAMV_D_L0_4x8: cb_mvd(L, C, 4 * i8, 1, 2); cb_mvd(L, C, 4 * i8 + 1, 1, 2); break;
+        default: for (int k = 0; k < 4; k++) cb_mvd(L, C, 4 * i8 + k, 1, 1); break;
+        }
+        prim_cab_residual_part(F, L, C, i8);
+        const int f8 = prim_cab_end(L, C, 0);
+        bits = ((unsigned long long)(unsigned)f8 * (unsigned long long)F.lambda2 + 128ull) >> 8;
+    } else
+        bits = (unsigned long long)(unsigned)prim_cavlc_part8(F, L, i8) * (unsigned long long)F.lambda2;
+    return (ssd << 8) + bits;
+}
 /* One RD trial of the mode the cache describes.  The trials run in the order the decision compares them (16x16, 16x8, 8x16, 8x8,
  * strict <), so the one that is the cheapest so far is the decision's winner as far as it has come: its products are kept
  * (prim_rd_keep), and the macroblock as decided is not encoded and walked a second time when it is the kept one (mbk_search).
@@ -827,6 +857,7 @@ PCAMV_DEV int rd_trial(const FrameDev &F, MBLocal *L, int counts)
     if (counts && cost < L->snap_cost) { L->snap_cost = cost; L->snap_part = L->i_partition; prim_rd_keep(F, L); }
     return cost;
 }
+template <int TESA>
 PCAMV_DEV void analyse_p_rd(const FrameDev &F, MBLocal *L, struct Analysis *a, int i_satd)
 {
     const int thresh = i_satd * 5 / 4;
@@ -835,7 +866,31 @@ PCAMV_DEV void analyse_p_rd(const FrameDev &F, MBLocal *L, struct Analysis *a, i
     a->me16x16.cost = a->rd16x16;
     if (a->cost16x8 <= thresh) { L->i_partition = PCAMV_D_16x8; update_cache(L, a); a->cost16x8 = rd_trial(F, L, 1); } else a->cost16x8 = PCAMV_COST_MAX;
     if (a->cost8x16 <= thresh) { L->i_partition = PCAMV_D_8x16; update_cache(L, a); a->cost8x16 = rd_trial(F, L, 1); } else a->cost8x16 = PCAMV_COST_MAX;
-    if (a->cost8x8 <= thresh) { L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8; update_cache(L, a); a->cost8x8 = rd_trial(F, L, F.embed); } else a->cost8x8 = PCAMV_COST_MAX;
+    if (a->cost8x8 <= thresh) {
+        L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8;
+        if (RD_PSUB_ON) {
+            /* analyse.c:2150-2180: per 8x8 the sub-partition shapes whose SATD cost is within 5/4 of the best are priced with
+             * x264_rd_cost_part, the 8x8 shape itself only if another one was.  No update of the whole cache here: it holds what the
+             * last trial / search left, and the trials of one 8x8 see what the others' left behind (non-zero flags, MV differences) */
+            for (int i = 0; i < 4; i++) {
+                const int c0 = a->cost4x4[i], c1 = a->cost8x4[i], c2 = a->cost4x8[i], c3 = a->me8x8[i].cost;
+                const int th = imin(imin(c0, c1), imin(c2, c3)) * 5 / 4;
+                int btype = PCAMV_D_L0_8x8;
+                unsigned long long bcost = ~0ull;
+                for (int subtype = PCAMV_D_L0_4x4; subtype <= PCAMV_D_L0_8x8; subtype++) {
+                    const int c = subtype == 0 ? c0 : subtype == 1 ? c1 : subtype == 2 ? c2 : c3;
+                    if (c > th || (subtype == PCAMV_D_L0_8x8 && bcost == ~0ull)) continue;
+                    L->sub_part[i] = (uint8_t)subtype;
+                    cache_mv_p8x8(L, a, i);
+                    const unsigned long long cost = rd_cost_part8(F, L, i);
+                    if (cost < bcost) { bcost = cost; btype = subtype; }
+                }
+                L->sub_part[i] = (uint8_t)btype;
+                cache_mv_p8x8(L, a, i);
+            }
+        } else update_cache(L, a);
+        a->cost8x8 = rd_trial(F, L, F.embed);
+    } else a->cost8x8 = PCAMV_COST_MAX;
 }
 /* what the entropy coder leaves behind for the following macroblocks (encoder.c:1900-1927, common/macroblock.c:1254-1400):
  * the context states adapted to the macroblock as coded, its non-zero flags / counts, coded block pattern and MV differences */
@@ -1112,6 +1167,7 @@ PCAMV_DEV int analyse_s16(const FrameDev &F, MBLocal *L, Analysis *a)
     for (int i = 0; i < 4; i++) L->sub_part[i] = PCAMV_D_L0_8x8;
     L->i_partition = PCAMV_D_16x16;
     a->rd16x16 = a->cost8x8 = a->cost16x8 = a->cost8x16 = PCAMV_COST_MAX;      /* analyse.c:321-332 */
+    for (int i = 0; i < 4; i++) a->cost4x4[i] = a->cost8x4[i] = a->cost4x8[i] = PCAMV_COST_MAX;      /* (read by the RD stage whether analysed or not) */
     a->rd16_early = 0;
     L->snap_part = -1; L->snap_cost = PCAMV_COST_MAX;
     if (F.b_fast_pskip) {
@@ -1172,9 +1228,19 @@ PCAMV_DEV void analyse_decide(const FrameDev &F, MBLocal *L, Analysis *a)
          * bounds the RD trials; x264_rd_cost_mb decides the partition; P_8x8 only while embedding (analyse.c:2841) */
         int i16, i4;
         if (a->rd16_early) {                 /* analyse.c:1197-1202, see analyse_p16x16 */
+            /* (the reference's cache had these MVs BEFORE the other searches overwrote them; here the searches' MVs are put back
+             * after the trial: the sub-partition RD trials predict MVs from whatever the cache holds, analyse.c:2150) */
+            uint32_t keep_mv[16];
+            PCAMV_WAVE_SYNC();
+            FOR_CAND(i, 16) keep_mv[NB_SLOT(i)] = ((const uint32_t *)L->cmv)[SCAN8_0 + (i & 3) + 8 * (i >> 2)];
+            const int part_keep = L->i_partition;
             L->i_type = PCAMV_P_L0; L->i_partition = PCAMV_D_16x16;
             cache_mv_set(L, 0, 0, 4, 4, a->me16x16.mv[0], a->me16x16.mv[1]);
             a->rd16x16 = rd_trial(F, L, 1);
+            PCAMV_WAVE_SYNC();
+            FOR_CAND(i, 16) ((uint32_t *)L->cmv)[SCAN8_0 + (i & 3) + 8 * (i >> 2)] = keep_mv[NB_SLOT(i)];
+            PCAMV_WAVE_SYNC();
+            L->i_partition = part_keep;
         }
         const unsigned long long t_i = PROF_T();
         if (F.b_chroma_me) {
@@ -1184,7 +1250,7 @@ PCAMV_DEV void analyse_decide(const FrameDev &F, MBLocal *L, Analysis *a)
         } else intra_analyse(F, L, i_cost, &i16, &i4);
         PROF_ADD(16, t_i);
         const unsigned long long t_rd = PROF_T();
-        analyse_p_rd(F, L, a, imin(i_cost, imin(i16, i4)));
+        analyse_p_rd<TESA>(F, L, a, imin(i_cost, imin(i16, i4)));
         PROF_ADD(17, t_rd);
         i_type = PCAMV_P_L0; i_partition = PCAMV_D_16x16; i_cost = a->me16x16.cost;
         if (a->cost16x8 < i_cost) { i_cost = a->cost16x8; i_partition = PCAMV_D_16x8; }

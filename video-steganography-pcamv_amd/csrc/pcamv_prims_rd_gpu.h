@@ -24,7 +24,7 @@ __device__ __forceinline__ int bsum4(uint32_t v) { return (int)__builtin_amdgcn_
  * them, prim_mb_fetch_store puts them into LDS -- so that all of it, together with the caller's own neighbour loads, is ONE
  * memory round trip on the macroblock chain.  (One load + LDS store per role and branch used to be a dozen round trips in a row:
  * a store needs its value, so every branch waited for its own load.) */
-struct MbFetch { uint32_t fy, fc, role, s0, s1, t0, t1, t2, t3; int b0, b1; };
+struct MbFetch { uint32_t fy, fc, role, s0, s1, s2, t0, t1, t2, t3; int b0, b1; };
 __device__ __forceinline__ void prim_mb_fetch(const FrameDev &F, int mb_x_, int mb_y_, int nb_, int rd_, MbFetch &P)
 {
     const int mb_x = rfl(mb_x_), mb_y = rfl(mb_y_), nb = rfl(nb_), rd = rfl(rd_);
@@ -37,7 +37,7 @@ __device__ __forceinline__ void prim_mb_fetch(const FrameDev &F, int mb_x_, int 
         const int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
         P.fc = *(const uint32_t *)((plane ? F.fenc[2] : F.fenc[1]) + (size_t)(mb_y * 8 + row) * (F.w >> 1) + mb_x * 8 + c4 * 4);
     }
-    P.role = 0; P.b0 = P.b1 = 0; P.s0 = P.s1 = P.t0 = P.t1 = P.t2 = P.t3 = 0;
+    P.role = 0; P.b0 = P.b1 = 0; P.s0 = P.s1 = P.s2 = P.t0 = P.t1 = P.t2 = P.t3 = 0;
     if (!rd) return;
     /* every lane makes all three loads (its role's from the neighbour, the others' from this macroblock's own slots, ignored) and keeps
      * its role's result: loads inside the role branches each waited for their own data -- a round trip per role */
@@ -70,6 +70,10 @@ __device__ __forceinline__ void prim_mb_fetch(const FrameDev &F, int mb_x_, int 
         else { P.s0 = NB_LD32(src + lane); if (lane < 52) P.s1 = NB_LD32(src + 64 + lane); }
         P.t0 = F.cabac_tab[lane]; P.t1 = F.cabac_tab[64 + lane]; P.t2 = F.cabac_tab[128 + lane]; P.t3 = F.cabac_tab[192 + lane];
     }
+    if (F.inter & PCAMV_ANALYSE_PSUB8x8) {       /* the macroblock's own non-zero / mvd entries as the macroblock coded before it left them (PCAMV_CHAIN_NZ / _MVD) */
+        const uint32_t *src = (const uint32_t *)(xy == 0 ? F.cabac_init : F.cabac) + PCAMV_CHAIN_NZ / 4;
+        if (lane < 22) P.s2 = xy == 0 ? src[lane] : NB_LD32(src + lane);
+    }
 }
 __device__ __forceinline__ void prim_mb_fetch_store(const FrameDev &F, MBLocal *L, int rd_, const MbFetch &P)
 {
@@ -82,6 +86,12 @@ __device__ __forceinline__ void prim_mb_fetch_store(const FrameDev &F, MBLocal *
         const int xy = L->mb_xy, nb = L->neighbour;
         if (lane < 48) { L->nzc[lane] = 0; L->i4mode[lane] = -1; ((uint32_t *)L->cmvd)[lane] = 0; }
         PCAMV_WAVE_SYNC();
+        if (F.inter & PCAMV_ANALYSE_PSUB8x8) {
+            if (lane < 6) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) L->nzc[scan8_all_of(4 * lane + k)] = (uint8_t)(P.s2 >> (8 * k));
+            } else if (lane < 22) ((uint32_t *)L->cmvd)[scan8_of(lane - 6)] = P.s2;
+        }
         if (lane < 16) {
             const int k = lane & 7, is_left = lane >> 3;
             /* cache positions of the bottom row / right column entries: 4 luma, 2 Cb, 2 Cr */
@@ -372,6 +382,7 @@ __device__ __forceinline__ void prim_intra4_encode(const FrameDev &F, MBLocal *L
     if (LANE() == 0) {
 #pragma unroll
         for (int y = 0; y < 4; y++) *(uint32_t *)&IFD(L, bx, by + y) = r[y];
+        L->nzc[scan8_of(idx)] = (uint8_t)(nz != 0);     /* encoder/macroblock.c:135: stays in the cache (the sub-partition RD trials read it) */
     }
     PCAMV_WAVE_SYNC();
 }
@@ -559,7 +570,7 @@ struct CabBits { int bits, vbits; };
 #else
 #define PCAMV_RESIDUAL_FN __device__ __forceinline__
 #endif
-PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_)
+PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_, int part_)
 {
     CabBits out = {0, 0};
     const int commit = rfl(commit_);
@@ -573,7 +584,10 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_)
     int bits = 0, sbits = 0;            /* per-lane bits (map decisions, coded_block_flag chains) / wave-uniform bits (level chains) */
     const unsigned long long t_1 = PROF_T();
     /* ---- 1 */
-    const bool coded = lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) != 0 : lane < 24 ? (cbp_chroma & 2) != 0 : lane < 26 ? (cbp_chroma & 3) != 0 : false;
+    /* part >= 0: x264_partition_size_cabac of 8x8 `part` (encoder/cabac.c:1058-1074): its luma blocks when it is coded, its two chroma AC blocks */
+    const int part = rfl(part_);
+    const bool coded = part >= 0 ? (lane < 16 ? (lane >> 2) == part && ((cbp_luma >> part) & 1) != 0 : lane < 24 ? ((lane - 16) & 3) == part : false)
+                     : lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) != 0 : lane < 24 ? (cbp_chroma & 2) != 0 : lane < 26 ? (cbp_chroma & 3) != 0 : false;
     const int idx = lane < 24 ? lane : lane < 26 ? 25 + (lane - 24) : 0;
     const int count = lane < 16 ? 16 : lane < 24 ? 15 : 4;
     int flag = 0, inc = 0;
@@ -683,7 +697,13 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_)
 __device__ __forceinline__ void prim_cab_residual(const FrameDev &F, MBLocal *L, CabWalk &C, int commit_)
 {
     (void)F;
-    const CabBits r = cab_residual_walk(L, commit_);
+    const CabBits r = cab_residual_walk(L, commit_, -1);
+    C.vbits += r.vbits; C.bits += r.bits;
+}
+__device__ __forceinline__ void prim_cab_residual_part(const FrameDev &F, MBLocal *L, CabWalk &C, int i8)
+{
+    (void)F;
+    const CabBits r = cab_residual_walk(L, 0, i8);
     C.vbits += r.vbits; C.bits += r.bits;
 }
 
@@ -706,17 +726,26 @@ PCAMV_DEV int size_se_of(int v) { return size_ue_of((unsigned)(v <= 0 ? -v * 2 :
 /* x264_macroblock_write_cavlc as a bit counter (encoder/cavlc.c:290-600; rdo.c:41-47): one residual block per lane (0..15 luma,
  * 16..23 chroma AC, 24 / 25 chroma DC).  First every lane counts its coefficients (what the neighbours' nC reads, cavlc.c:133),
  * then sizes its block with nC from the counts.  Leaves the counts in L->nzc. */
-__device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
+/* part >= 0: x264_partition_size_cavlc of 8x8 `part` of a P_8x8 macroblock instead (encoder/cavlc.c:621-661): the sub-partition's MV
+ * differences, its luma blocks when it is coded, its two chroma AC blocks */
+__device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L, int part_ = -1)
 {
     PCAMV_WAVE_SYNC();
-    const int lane = LANE();
+    const int lane = LANE(), part = rfl(part_);
     const int cbp_luma = rfl(L->cbp_luma), cbp_chroma = rfl(L->cbp_chroma);
     int bits = 0;
     /* header: every lane the same walk, counted on lane 0 */
     {
         int hb = 0, mvp[2];
 #define GMVD(idx, w) (predict_mv(L, idx, w, mvp), size_se_of(L->cmv[scan8_of(idx)][0] - mvp[0]) + size_se_of(L->cmv[scan8_of(idx)][1] - mvp[1]))
-        if (L->i_type == PCAMV_P_8x8) {
+        if (part >= 0) {
+            switch (L->sub_part[part]) {
+            case PCAMV_D_L0_8x8: hb += GMVD(4 * part, 2); break;
+            case PCAMV_D_L0_8x4: hb += GMVD(4 * part, 2); hb += GMVD(4 * part + 2, 2); break;
+            case PCAMV_D_L0_4x8: hb += GMVD(4 * part, 1); hb += GMVD(4 * part + 1, 1); break;
+            default: for (int k = 0; k < 4; k++) hb += GMVD(4 * part + k, 1); break;
+            }
+        } else if (L->i_type == PCAMV_P_8x8) {
             hb += size_ue_of(3);
             for (int i = 0; i < 4; i++) { const int sp = L->sub_part[i]; hb += size_ue_of(sp == PCAMV_D_L0_8x8 ? 0 : sp == PCAMV_D_L0_8x4 ? 1 : sp == PCAMV_D_L0_4x8 ? 2 : 3); }
             for (int i = 0; i < 4; i++)
@@ -730,13 +759,16 @@ __device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
         else if (L->i_partition == PCAMV_D_16x8) { hb += size_ue_of(1); hb += GMVD(0, 4); hb += GMVD(8, 4); }
         else { hb += size_ue_of(2); hb += GMVD(0, 2); hb += GMVD(4, 2); }
 #undef GMVD
-        hb += size_ue_of(vlc_inter_cbp_golomb_dev[(cbp_chroma << 4) | cbp_luma]);
-        if (cbp_luma | cbp_chroma) hb += 1;          /* mb_qp_delta = 0 */
+        if (part < 0) {
+            hb += size_ue_of(vlc_inter_cbp_golomb_dev[(cbp_chroma << 4) | cbp_luma]);
+            if (cbp_luma | cbp_chroma) hb += 1;          /* mb_qp_delta = 0 */
+        }
         if (lane == 0) bits = hb;
     }
     /* which block this lane codes, and whether it is coded at all */
     const int idx = lane < 24 ? lane : 25 + (lane - 24);
-    const bool mine = lane < 26 && (lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) : lane < 24 ? (cbp_chroma & 2) != 0 : cbp_chroma != 0);
+    const bool mine = part >= 0 ? (lane < 16 ? (lane >> 2) == part && ((cbp_luma >> part) & 1) != 0 : lane < 24 && ((lane - 16) & 3) == part)
+                    : lane < 26 && (lane < 16 ? ((cbp_luma >> (lane >> 2)) & 1) : lane < 24 ? (cbp_chroma & 2) != 0 : cbp_chroma != 0);
     const int count = lane < 16 ? 16 : lane < 24 ? 15 : 4;
     const int p8 = scan8_all_of(lane < 26 ? idx : 0);
     int level[16], total = 0, last = -1, trailing = 0;
@@ -784,6 +816,73 @@ __device__ __forceinline__ int prim_cavlc_mb(const FrameDev &F, MBLocal *L)
     (void)F;
     PCAMV_WAVE_SYNC();
     return sum;
+}
+
+__device__ __forceinline__ int prim_cavlc_part8(const FrameDev &F, MBLocal *L, int i8) { return prim_cavlc_mb(F, L, i8); }
+
+/* ---------------------------------------------------------------- x264_rd_cost_part for one 8x8 of a P_8x8 macroblock */
+/* x264_macroblock_encode_p8x8 (encoder/macroblock.c:929-1052): prediction with the sub-partition's MVs (the cache), the 8x8's four
+ * luma blocks with their own decimation rule (dropped below a score of 4), its two chroma 4x4 blocks without their DC; levels,
+ * non-zero flags and reconstruction stay.  One block per lane like prim_mb_transform: the 8x8's luma blocks are the quad of
+ * lanes 4 i8 .. 4 i8 + 3, its chroma blocks lanes 16 + i8 and 20 + i8. */
+__device__ __forceinline__ void prim_encode_p8x8(const FrameDev &F, MBLocal *L, int i8_)
+{
+    const int i8 = rfl(i8_);
+    prim_predict_mb(F, L, 0);               /* (the whole macroblock: only this 8x8's pixels are looked at) */
+    const int lane = LANE();
+    const bool is_l = lane < 16 && (lane >> 2) == i8, is_c = lane >= 16 && lane < 24 && ((lane - 16) & 3) == i8;
+    const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+    const int px = lane < 16 ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4, py = lane < 16 ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
+    int16_t d[16];
+    int nz = 0, score = 0, rawdc = 0;
+    if (is_l || is_c) residual_block(F, L, px, py, lane < 16, d, &nz, &score, &rawdc, L->coef[lane < 24 ? lane : 0]);
+    const int sc = (is_l && nz && F.b_dct_decimate) ? score : 0, nzl = is_l ? nz : 0;
+    int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8);
+    int any8 = nzl | dpp_qp1(nzl); any8 |= dpp_qp2(any8);
+    const bool keep = any8 != 0 && !(F.b_dct_decimate && q8 < 4);
+    uint8_t *dst = L->pred + py * 16 + px;
+    if (is_l) { if (keep && nz) idct4x4_add(dst, d); L->nzc[scan8_of(lane)] = (uint8_t)(keep && nz); }
+    else if (is_c) { if (nz) idct4x4_add(dst, d); L->nzc[scan8_all_of(lane)] = (uint8_t)nz; }
+    const unsigned long long km = __ballot(is_l && keep);
+    L->cbp_luma = (L->cbp_luma & ~(1 << i8)) | (km ? 1 << i8 : 0);
+    L->cbp_chroma = 2;
+    PCAMV_WAVE_SYNC();
+}
+/* ssd_plane( PIXEL_8x8, luma ) + ssd_plane( PIXEL_4x4, U / V ) of that 8x8 (rdo.c:106-128); psy: hadamard_ac of the 8x8 against the
+ * source's energies of the same 8x8 (sum_satd / sum_sa8d, rdo.c:65-93), computed here rather than kept per block */
+__device__ __forceinline__ int prim_ssd_part8(const FrameDev &F, MBLocal *L, int i8_)
+{
+    const int i8 = rfl(i8_);
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    const bool is_l = lane < 16 && (lane >> 2) == i8, is_c = lane >= 16 && lane < 24 && ((lane - 16) & 3) == i8;
+    int v = 0;
+    if (is_l || is_c) {
+        const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
+        const int px = lane < 16 ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4, py = lane < 16 ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t e = lds4(L->fenc + (py + k) * 16 + px), p = lds4(L->pred + (py + k) * 16 + px);
+#pragma unroll
+            for (int x = 0; x < 4; x++) { const int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += mul24s(dd, dd); }
+        }
+    }
+    int ssd = wave_sum_all(v);
+    if (F.psy_rd) {
+        int s4, dc, s8, f4, fdc, f8;
+        had_lane_sums(L->pred, lane, &s4, &dc, &s8);
+        had_lane_sums(L->fenc, lane, &f4, &fdc, &f8);
+        int fs = (f4 >> 1) - (fdc >> 1);
+        if (!is_l) { s4 = 0; dc = 0; s8 = 0; fs = 0; fdc = 0; f8 = 0; }
+        s4 = group_sum(s4, 16); dc = group_sum(dc, 16); s8 = group_sum(s8, 16); fs = group_sum(fs, 16); fdc = group_sum(fdc, 16); f8 = group_sum(f8, 16);
+        const int S4 = __builtin_amdgcn_readlane(s4, 0), DC = __builtin_amdgcn_readlane(dc, 0), S8 = __builtin_amdgcn_readlane(s8, 0);
+        const int FS = __builtin_amdgcn_readlane(fs, 0), FDC = __builtin_amdgcn_readlane(fdc, 0), F8 = __builtin_amdgcn_readlane(f8, 0);
+        const int sum4 = (S4 - DC) >> 1, sum8 = (S8 - DC) >> 2, fsa8d = ((F8 + 2) >> 2) - (FDC >> 2);
+        const int satd = (iabs(sum4 - FS) + iabs(sum8 - fsa8d)) >> 1;
+        ssd += (satd * F.psy_rd * F.lambda + 128) >> 8;
+    }
+    PCAMV_WAVE_SYNC();
+    return ssd;
 }
 
 /* what the coded macroblock leaves for its neighbours and successors: bottom row / right column of the non-zero cache, coded
@@ -845,6 +944,15 @@ __device__ __forceinline__ void prim_rd_commit(const FrameDev &F, MBLocal *L, in
             for (int i = 0; i < 460; i++) h = (h ^ L_CAB(L, 0)[i]) * 16777619u;
             F.dbg_hash[xy] = h;
         }
+    }
+    if (F.inter & PCAMV_ANALYSE_PSUB8x8) {
+        uint32_t *dst = (uint32_t *)F.cabac + PCAMV_CHAIN_NZ / 4;
+        if (lane < 6) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) w |= (uint32_t)(skip ? 0 : L->nzc[scan8_all_of(4 * lane + k)]) << (8 * k);
+            NB_ST32(dst + lane, w);
+        } else if (lane < 22) NB_ST32(dst + lane, ((const uint32_t *)L->cmvd)[scan8_of(lane - 6)]);
     }
     PCAMV_WAVE_SYNC();
 }

@@ -22,19 +22,25 @@
 #ifndef PCAMV_NO_RESIDUAL_CALL
 #define PCAMV_RESIDUAL_CALL 1      /* pcamv_prims_rd_gpu.h: the CABAC residual walk as a function of its own */
 #endif
+/* variant mask of the control code (pcamv_logic.h): 2 = RD mode decision, 4 = speculative raster chain, 8 = sub-8x8 partitions priced by
+ * x264_rd_cost_part -- only in the two one-wave-per-SIMD builds, which have the registers for it (compiled into the 4-waves-per-SIMD
+ * build it cost 22 spilled VGPRs); batches with --partitions p4x4 at --subme >= 6 run on those (pcamv_gpu_batch_create) */
 #if defined(PCAMV_RD_SPEC)          /* pcamv_rd_spec*.hip: the speculative raster chain, PCAMV_RD_SPEC = waves per SIMD (1, 2 or 4) */
 #if PCAMV_RD_SPEC == 1
 #define PCAMV_RD_LO 1
 #define RD_NAME(x) x##_spec
+#define PCAMV_RD_VARIANT 14
 #elif PCAMV_RD_SPEC == 2
 #define RD_NAME(x) x##_spec2
+#define PCAMV_RD_VARIANT 6
 #else
 #define RD_NAME(x) x##_spec4
+#define PCAMV_RD_VARIANT 6
 #endif
 #define PCAMV_RD_OCC PCAMV_RD_SPEC
-#define PCAMV_RD_VARIANT 6
 #elif defined(PCAMV_RD_LO)
 #define PCAMV_RD_OCC 1
+#define PCAMV_RD_VARIANT 10
 #define RD_NAME(x) x##_lo
 #else
 #ifndef PCAMV_RD_OCC
