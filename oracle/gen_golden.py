@@ -256,6 +256,7 @@ if __name__ == "__main__":
         analysis_fixture("qcif_hex_subme6_psub8", 176, 144, "hex", 6, 26, 0x30, 61, 0, noise=30)
         analysis_fixture("qcif_hex_subme7_psub8_cavlc", 176, 144, "hex", 7, 20, 0x30, 62, 32, cabac=0, noise=40)
         analysis_fixture("qcif_umh_subme6_psub8", 176, 144, "umh", 6, 34, 0x30, 63, 0, noise=25)
+        analysis_fixture("qcif_tesa_subme6", 176, 144, "tesa", 6, 26, 0x10, 81, 0, noise=20)      # the RD decision after the Hadamard exhaustive search
         sys.exit(0)
     if "--rd-only" in sys.argv:
         rd_primitive_fixture()

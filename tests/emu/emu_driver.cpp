@@ -12,6 +12,8 @@
 #include "pcamv_mbkernels.h"
 #include "pcamv_host_tables.h"
 
+/* the instance the library would run: the --me tesa one (variant bit 0) only for that method; bit 1 the RD mode decision, bit 3 x264_rd_cost_part */
+#define EMU_SEARCH(F, L, a, x, y) do { if ((F).me_method == PCAMV_ME_TESA) mbk_search<11>(F, L, a, x, y); else mbk_search<10>(F, L, a, x, y); } while (0)
 extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
                                   const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                                   uint8_t *luma4, uint8_t *cu, uint8_t *cv,
@@ -47,21 +49,21 @@ extern "C" int emu_analyse_pframe(const pcamv_params_t *p, int qp, int embed,
     MBLocal *L = (MBLocal *)malloc(sizeof(MBLocal));
     Analysis *a = (Analysis *)malloc(sizeof(Analysis));
     if (diag_order == 3) {  /* raster order, fused: what the dataflow schedule does when the entropy coder is CABAC (one chain per frame) */
-        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) { mbk_search<11>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); }
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) { EMU_SEARCH(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux); free(F.nb_nz); free(F.nb_cbp); free(F.nb_mvd);
         return 0;
     }
     if (diag_order == 2) {  /* dataflow schedule: search, then RCA + reconstruction of the same macroblock, in a dependency-legal order */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { mbk_search<11>(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); } }
+            for (int y = F.mb_h - 1; y >= 0; y--) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) { EMU_SEARCH(F, L, a, x, y); mbk_rca_encode(F, L, a, y * F.mb_w + x, 1, F.b_mbrd); } }
         free(L); free(a); free(cost); free(F.mb_type); free(F.mv); free(F.ref8); free(F.mvr); free(F.mvp_aux);
         return 0;
     }
     if (diag_order) {       /* the order the GPU uses: anti-diagonals x + 2y = d */
         for (int d = 0; d < F.mb_w + 2 * (F.mb_h - 1); d++)
-            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) mbk_search<11>(F, L, a, x, y); }
+            for (int y = 0; y < F.mb_h; y++) { int x = d - 2 * y; if (x >= 0 && x < F.mb_w) EMU_SEARCH(F, L, a, x, y); }
     } else
-        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) mbk_search<11>(F, L, a, x, y);
+        for (int y = 0; y < F.mb_h; y++) for (int x = 0; x < F.mb_w; x++) EMU_SEARCH(F, L, a, x, y);
     if (embed)
         for (int xy = F.n_mb - 1; xy >= 0; xy--) for (int k = 15; k >= 0; k--) mbk_rca(F, L, a, xy, k);
     for (int xy = 0; xy < F.n_mb; xy++) mbk_encode(F, L, a, xy);

@@ -10,7 +10,7 @@ ANALYSIS_FIXTURES = ["qcif_hex_subme5", "qcif_dia_subme2", "qcif_umh_subme4_psub
 # --subme 6 / 7 (RD mode decision): CABAC and CAVLC sizes, psy-RD on / off, embedding off (no P_8x8 then, analyse.c:2841)
 RD_FIXTURES = ["qcif_hex_subme6", "qcif_umh_subme7_cavlc", "qcif_dia_subme6_nopsy_noisy", "qcif_esa_subme6_noembed", "cif_umh_subme7",
                # sub-8x8 partitions priced by x264_rd_cost_part (rdo.c:202-245)
-               "qcif_hex_subme6_psub8", "qcif_hex_subme7_psub8_cavlc", "qcif_umh_subme6_psub8"]
+               "qcif_hex_subme6_psub8", "qcif_hex_subme7_psub8_cavlc", "qcif_umh_subme6_psub8", "qcif_tesa_subme6"]
 
 
 def fixture_params(g, make_params, **over):

@@ -232,6 +232,9 @@ RD_SWEEP = [
     (176, 144, "umh", 7, 18, 68, 32, 0, 1.0, 40, 1, 0x30),   # CAVLC: non-zero COUNTS left over between the trials
     (320, 240, "dia", 6, 32, 69, 64, 1, 0.5, 25, 1, 0x30),
     (64, 48, "hex", 6, 24, 70, 0, 1, 1.0, 35, 1, 0x30),      # 4 macroblocks wide: too narrow for the speculative chain (plain one-wave-per-SIMD build)
+    # --me tesa at the RD levels (pcamv_rd_tesa.hip): CAVLC (wavefront order), and with sub-8x8 partitions
+    (176, 144, "tesa", 7, 30, 82, 32, 0, 1.0, 30, 1),
+    (176, 144, "tesa", 6, 22, 83, 0, 1, 1.0, 30, 1, 0x30),
 ]
 
 
@@ -365,9 +368,8 @@ def test_open_rejects_unsupported(pc):
     pc.param_parse(p, "partitions", "all")   # subme 6 (the default) with sub-8x8 partitions: x264_rd_cost_part, built in round 3
     pc.Encoder(p).close()
     p = pc.param_default(176, 144)
-    pc.param_parse(p, "me", "tesa")          # the default subme 6 with --me tesa: not built
-    with pytest.raises(pc.PcamvError):
-        pc.Encoder(p)
+    pc.param_parse(p, "me", "tesa")          # the default subme 6 with --me tesa: built in round 3
+    pc.Encoder(p).close()
     p = pc.param_default(170, 144)
     with pytest.raises(pc.PcamvError):
         pc.Encoder(p)

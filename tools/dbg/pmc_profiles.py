@@ -1,6 +1,6 @@
 """Turn the per-kernel counter sums that `tools/dbg/pmc_sq.sh <gops> <tag>` and `tools/dbg/pmc_cache_ab.sh <gops> <tag>` leave under
 gpurun_out/ (pmc_<tag>_{a,b,c,fetch,write,l2,l1}.json; the raw rocprofv3 CSVs are aggregated on the box, they exceed what gpurun
-returns) into the committed summaries profiles/r02_pmc_traffic_<name>.json and profiles/r02_pmc_sq_summary_<name>.json, which bench.py
+returns) into the committed summaries profiles/{RND}_pmc_traffic_<name>.json and profiles/{RND}_pmc_sq_summary_<name>.json, which bench.py
 quotes (labelled with their source).   usage: python tools/dbg/pmc_profiles.py <tag> <gops> [name] [kernel] [waves per SIMD]"""
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/"
@@ -8,6 +8,7 @@ tag, gops = sys.argv[1], int(sys.argv[2])
 name = sys.argv[3] if len(sys.argv) > 3 else "rd"
 kern = sys.argv[4] if len(sys.argv) > 4 else "k_analyse_flow_rd"
 wps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+RND = os.environ.get("PCAMV_ROUND", "r03")
 mbs = gops * 8160
 
 
@@ -32,7 +33,7 @@ if tf and tw:
     for grp in ("l2", "l1"):
         t = load(grp)
         if t: out[grp + "_per_mb"] = {c: v['sum'] / v['dispatches'] / mbs for c, v in t[kern].items()}
-    json.dump(out, open(R + f'profiles/r02_pmc_traffic_{name}.json', 'w'), indent=1)
+    json.dump(out, open(R + f'profiles/{RND}_pmc_traffic_{name}.json', 'w'), indent=1)
     print("traffic B/MB", round(fetch), "+", round(write))
 d, nd = {}, 0
 for p in 'abc':
@@ -53,5 +54,5 @@ res = {"command": f"tools/dbg/pmc_sq.sh {gops} {tag} (three rocprofv3 --pmc pass
        "macroblocks_per_dispatch": mbs, "dispatches": nd, "per_dispatch": d, "per_macroblock": per_mb, "summary": summary,
        "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); issue_slots_used = waves/SIMD x ACTIVE_INST_ANY / WAVE_CYCLES "
                 "= average number of the SIMD's resident waves that are executing an instruction; wave_waiting_s_waitcnt = share of a wave's life parked on s_waitcnt"}
-json.dump(res, open(R + f'profiles/r02_pmc_sq_summary_{name}.json', 'w'), indent=1)
+json.dump(res, open(R + f'profiles/{RND}_pmc_sq_summary_{name}.json', 'w'), indent=1)
 print(json.dumps(summary))

@@ -90,6 +90,7 @@ int pcamv_rd_prof_fetch(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_lo(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_spec(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_spec2(unsigned long long *out, int reset);
+int pcamv_rd_prof_fetch_tesa(unsigned long long *out, int reset);
 int pcamv_rd_prof_fetch_spec4(unsigned long long *out, int reset);
 extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
 {
@@ -105,6 +106,8 @@ extern "C" int pcamv_gpu_prof_fetch(unsigned long long *out, int reset)
     if (pcamv_rd_prof_fetch_spec2(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     if (pcamv_rd_prof_fetch_spec4(rd, reset)) return -1;
+    for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
+    if (pcamv_rd_prof_fetch_tesa(rd, reset)) return -1;
     for (int i = 0; i < PCAMV_PROF_N; i++) out[i] += rd[i];
     return 0;
 }
@@ -226,8 +229,10 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
             b->rd_lo = !b->rd_spec && (inst && strncmp(inst, "spec", 4) ? !strcmp(inst, "lo") : (b->fl.raster && n <= 2 * n_cu));
             /* sub-8x8 partitions at this level (x264_rd_cost_part): compiled into the two one-wave-per-SIMD builds only */
             if (ctxs[0]->p.inter & PCAMV_ANALYSE_PSUB8x8) { if (b->rd_spec) b->rd_spec = 1; else b->rd_lo = 1; }
+            /* --me tesa: its own build (pcamv_rd_tesa.hip), plain chain */
+            if (b->b_tesa) { b->rd_spec = 0; b->rd_lo = 0; }
             b->fl.spec = b->rd_spec != 0;
-            per_cu = b->rd_spec == 1 ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_spec == 2 ? pcamv_flow_rd_waves_per_cu_spec2() :
+            per_cu = b->b_tesa ? pcamv_flow_rd_waves_per_cu_tesa() : b->rd_spec == 1 ? pcamv_flow_rd_waves_per_cu_spec() : b->rd_spec == 2 ? pcamv_flow_rd_waves_per_cu_spec2() :
                      b->rd_spec == 4 ? pcamv_flow_rd_waves_per_cu_spec4() : b->rd_lo ? pcamv_flow_rd_waves_per_cu_lo() : pcamv_flow_rd_waves_per_cu();
             if (per_cu < 0) e = hipErrorUnknown;
         }
@@ -316,8 +321,6 @@ extern "C" int pcamv_gpu_open(const pcamv_params_t *p, int device, pcamv_ctx_t *
     *out = NULL;
     if (p->i_width <= 0 || p->i_height <= 0 || p->i_width % 16 || p->i_height % 16) return PCAMV_EINVAL;
     if (p->i_subpel_refine < 1 || p->i_subpel_refine > 7) return PCAMV_EUNSUP;   /* 8, 9: RD refinement of the MVs (disabled in the fork's P frames anyway, analyse.c:3112) */
-    /* RD mode decision (6, 7): not with --me tesa (its survivor list and the context states want the same LDS) */
-    if (p->i_subpel_refine >= 6 && p->i_me_method == PCAMV_ME_TESA) return PCAMV_EUNSUP;
     if (p->i_me_method < PCAMV_ME_DIA || p->i_me_method > PCAMV_ME_TESA) return PCAMV_EUNSUP;
     if (p->i_me_method == PCAMV_ME_TESA && p->i_me_range > TESA_MAX_RANGE) return PCAMV_EUNSUP;      /* the survivor list lives in LDS: 32 x 33 positions */
     if (p->i_me_range < 4 || p->i_me_range > 64 || p->i_mv_range < 32) return PCAMV_EINVAL;
@@ -537,7 +540,8 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
             hipLaunchKernelGGL(k_flow_init, dim3((b->fl.total + 255) / 256), dim3(256), 0, st, b->fl);
             if (timed) { ev = b->ev_head; hipEventRecord(b->ev0[ev], st); }
             if (F.b_mbrd) {
-                if (b->rd_spec == 1) pcamv_launch_flow_rd_spec((unsigned)b->flow_waves, st, dF, b->fl);
+                if (b->b_tesa) pcamv_launch_flow_rd_tesa((unsigned)b->flow_waves, st, dF, b->fl);
+                else if (b->rd_spec == 1) pcamv_launch_flow_rd_spec((unsigned)b->flow_waves, st, dF, b->fl);
                 else if (b->rd_spec == 2) pcamv_launch_flow_rd_spec2((unsigned)b->flow_waves, st, dF, b->fl);
                 else if (b->rd_spec == 4) pcamv_launch_flow_rd_spec4((unsigned)b->flow_waves, st, dF, b->fl);
                 else if (b->rd_lo) pcamv_launch_flow_rd_lo((unsigned)b->flow_waves, st, dF, b->fl);

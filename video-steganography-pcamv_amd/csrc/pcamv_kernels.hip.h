@@ -680,6 +680,8 @@ void pcamv_launch_flow_rd_lo(unsigned waves, hipStream_t st, const FrameDev *dF,
 int pcamv_flow_rd_waves_per_cu_lo(void);
 void pcamv_launch_flow_rd_spec(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu_spec(void);
+void pcamv_launch_flow_rd_tesa(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
+int pcamv_flow_rd_waves_per_cu_tesa(void);
 void pcamv_launch_flow_rd_spec2(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);
 int pcamv_flow_rd_waves_per_cu_spec2(void);
 void pcamv_launch_flow_rd_spec4(unsigned waves, hipStream_t st, const FrameDev *dF, const FlowDev &fl);

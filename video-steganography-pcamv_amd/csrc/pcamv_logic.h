@@ -845,6 +845,12 @@ PCAMV_DEV unsigned long long rd_cost_part8(const FrameDev &F, MBLocal *L, int i8
         bits = ((unsigned long long)(unsigned)f8 * (unsigned long long)F.lambda2 + 128ull) >> 8;
     } else
         bits = (unsigned long long)(unsigned)prim_cavlc_part8(F, L, i8) * (unsigned long long)F.lambda2;
+#if defined(PCAMV_TRACE) && !defined(PCAMV_HOST_EMU)      /* diagnostics build only */
+    if (F.trace && L->mb_xy == F.trace_mb && LANE() == 0) {
+        int k = F.trace[0];
+        if (k < 4000) { int *t = F.trace + 1 + 8 * k; t[0] = -1; t[1] = i8; t[2] = L->sub_part[i8]; t[3] = (int)ssd; t[4] = (int)bits; t[5] = L->cbp_luma; t[6] = L->cmv[scan8_of(4 * i8)][0]; t[7] = L->cmv[scan8_of(4 * i8)][1]; F.trace[0] = k + 1; }
+    }
+#endif
     return (ssd << 8) + bits;
 }
 /* One RD trial of the mode the cache describes.  The trials run in the order the decision compares them (16x16, 16x8, 8x16, 8x8,
@@ -868,7 +874,14 @@ PCAMV_DEV void analyse_p_rd(const FrameDev &F, MBLocal *L, struct Analysis *a, i
     if (a->cost8x16 <= thresh) { L->i_partition = PCAMV_D_8x16; update_cache(L, a); a->cost8x16 = rd_trial(F, L, 1); } else a->cost8x16 = PCAMV_COST_MAX;
     if (a->cost8x8 <= thresh) {
         L->i_type = PCAMV_P_8x8; L->i_partition = PCAMV_D_8x8;
-        if (RD_PSUB_ON) {
+        /* (the flag is read again here, through an empty asm: in the --me tesa instance hipcc (ROCm 7.2) tested a copy of "no sub-8x8
+         * partitions" it had made ~60 k instructions earlier in a caller-saved scalar pair, s[40:41], which the search function
+         * called in between uses as scratch -- the branch went the wrong way with the flag itself intact) */
+        unsigned inter_now = F.inter;
+#ifndef PCAMV_HOST_EMU
+        asm volatile("" : "+s"(inter_now));
+#endif
+        if ((TESA & 8) && (inter_now & PCAMV_ANALYSE_PSUB8x8)) {
             /* analyse.c:2150-2180: per 8x8 the sub-partition shapes whose SATD cost is within 5/4 of the best are priced with
              * x264_rd_cost_part, the 8x8 shape itself only if another one was.  No update of the whole cache here: it holds what the
              * last trial / search left, and the trials of one 8x8 see what the others' left behind (non-zero flags, MV differences) */

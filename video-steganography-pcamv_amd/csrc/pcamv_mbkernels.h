@@ -83,9 +83,22 @@ template <int TESA>
 PCAMV_DEV void mbk_search(const FrameDev &F, MBLocal *L, Analysis *a, int mb_x, int mb_y)
 {
     const unsigned long long t_l = PROF_T();
-    mb_load(F, L, mb_x, mb_y, 0, MBRD_ON);
-    PROF_ADD(11, t_l);
-    analyse_mb_search<TESA>(F, L, a);
+    if ((TESA & 3) == 3 && F.b_mbrd) {
+        /* --me tesa with the RD mode decision: the Hadamard exhaustive search keeps its survivor list in the LDS the RD stage keeps
+         * the context states in (TESA_SLOT / L_CAB), so what the RD stage needs from memory is fetched after the searches, not with
+         * the macroblock's other loads */
+        mb_load(F, L, mb_x, mb_y, 0, 0);
+        PROF_ADD(11, t_l);
+        const int skip = analyse_s16<TESA>(F, L, a);
+        if (!skip) analyse_s_rest<TESA>(F, L, a);
+        { MbFetch pf; prim_mb_fetch(F, mb_x, mb_y, L->neighbour, 1, pf); prim_mb_fetch_store(F, L, 1, pf); }
+        if (!skip) analyse_decide<TESA>(F, L, a);
+        update_cache(L, a);
+    } else {
+        mb_load(F, L, mb_x, mb_y, 0, MBRD_ON);
+        PROF_ADD(11, t_l);
+        analyse_mb_search<TESA>(F, L, a);
+    }
     mbk_search_finish<TESA>(F, L, a, mb_x, mb_y);
 }
 

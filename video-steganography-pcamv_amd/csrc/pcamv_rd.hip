@@ -38,6 +38,11 @@
 #define PCAMV_RD_VARIANT 6
 #endif
 #define PCAMV_RD_OCC PCAMV_RD_SPEC
+#elif defined(PCAMV_RD_TESA)        /* pcamv_rd_tesa.hip: the RD mode decision after the Hadamard exhaustive search (--me tesa), one wave per SIMD */
+#define PCAMV_RD_LO 1
+#define PCAMV_RD_OCC 1
+#define PCAMV_RD_VARIANT 11
+#define RD_NAME(x) x##_tesa
 #elif defined(PCAMV_RD_LO)
 #define PCAMV_RD_OCC 1
 #define PCAMV_RD_VARIANT 10

@@ -133,7 +133,7 @@ def lib_path():
 
 def build_library(force=False):
     """hipcc --offload-arch=gfx950 of csrc/pcamv_gpu.hip (+ csrc/pcamv_tesa.hip, the --me tesa instance, and csrc/pcamv_rd.hip + csrc/pcamv_rd_lo.hip
-    + csrc/pcamv_rd_spec{,2,4}.hip, the five builds of the --subme 6 / 7 instance, compiled side by side) into the in-tree libpcamv_gpu.so."""
+    + csrc/pcamv_rd_spec{,2,4}.hip + csrc/pcamv_rd_tesa.hip, the six builds of the --subme 6 / 7 instance, compiled side by side) into the in-tree libpcamv_gpu.so."""
     out = lib_path()
     srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if not f.endswith(".o")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "pcamv_gpu.h"))
@@ -141,7 +141,7 @@ def build_library(force=False):
         return out
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
     objs, procs = [], []
-    for unit in ("pcamv_gpu", "pcamv_tesa", "pcamv_rd", "pcamv_rd_lo", "pcamv_rd_spec", "pcamv_rd_spec2", "pcamv_rd_spec4"):
+    for unit in ("pcamv_gpu", "pcamv_tesa", "pcamv_rd", "pcamv_rd_lo", "pcamv_rd_spec", "pcamv_rd_spec2", "pcamv_rd_spec4", "pcamv_rd_tesa"):
         obj = os.path.join(_CSRC, unit + ".o")
         objs.append(obj)
         procs.append(subprocess.Popen(["hipcc", *flags, "-c", "-o", obj, os.path.join(_CSRC, unit + ".hip")]))
@@ -258,7 +258,7 @@ class Encoder:
         rc = self.lib.pcamv_gpu_open(C.byref(params), device, C.byref(ctx))
         if rc:
             names = {-1: "invalid parameter", -2: "no HIP device (there is no CPU fallback)", -3: "out of memory",
-                     -4: "HIP error", -5: "unsupported (subme >= 8, subme >= 6 with p4x4 partitions or --me tesa, tesa with me_range > 16, ... are not on the GPU path)"}
+                     -4: "HIP error", -5: "unsupported (subme >= 8, tesa with me_range > 16, ... are not on the GPU path)"}
             raise PcamvError(f"pcamv_gpu_open failed: {names.get(rc, rc)}")
         self.ctx = ctx
 
