@@ -63,7 +63,8 @@ typedef struct pcamv_params_t {
     int32_t i_width, i_height;        /* luma size, multiples of 16                              */
     int32_t i_me_method;              /* analyse.i_me_method  (PCAMV_ME_*, all five)             */
     int32_t i_me_range;               /* analyse.i_me_range   (default 16, common.c:121); <= 16 with PCAMV_ME_TESA */
-    int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..7 (6 and 7 are the same for P frames: RD mode decision) */
+    int32_t i_subpel_refine;          /* analyse.i_subpel_refine, 1..7 (6 and 7 are the same for P frames: RD mode decision, incl.
+                                         x264_rd_cost_part for sub-8x8 partitions); 8 / 9 (RD refinement of MVs: off in the fork's P frames) PCAMV_EUNSUP */
     int32_t i_mv_range;               /* analyse.i_mv_range after level lookup, encoder.c:558    */
     int32_t b_chroma_me;              /* analyse.b_chroma_me  (default 1)                        */
     int32_t b_fast_pskip;             /* analyse.b_fast_pskip (default 1)                        */
@@ -78,9 +79,10 @@ typedef struct pcamv_params_t {
                                          0 below; the caller also lowers i_chroma_qp_offset as encoder.c:520-521 does */
 } pcamv_params_t;
 
-/* One macroblock of the pass-1 record: same members, order of blocks and meaning as
- * h->info.cache[] (common/common.h:585-603).  mv[] / ref[] use x264's block-index order
- * 0 1 4 5 / 2 3 6 7 / 8 9 12 13 / 10 11 14 15 (analyse.c:2893-2898). */
+/* One macroblock of the pass-1 record: the members of h->info.cache[] (common/common.h:585-603) that this path produces, under
+ * their names and with their meaning; the ORDER of the members differs and the reference's (anonymous) struct carries more
+ * (intra fields), so a host copies member by member (integration/pcamv_x264_glue.c).  mv[] / ref[] use x264's block-index
+ * order 0 1 4 5 / 2 3 6 7 / 8 9 12 13 / 10 11 14 15 (analyse.c:2893-2898). */
 typedef struct pcamv_mb_t {
     int32_t i_type;                   /* PCAMV_P_L0 | PCAMV_P_8x8 | PCAMV_P_SKIP                 */
     int32_t i_partition;              /* PCAMV_D_16x16 | 16x8 | 8x16 | 8x8                       */
