@@ -708,6 +708,82 @@ def test_rd_instances_agree(pc, monkeypatch, inst):
     test_rd_mode_decision_matches_oracle(pc, RD_SWEEP[0])
 
 
+FINAL_SLICES = ["pslice_qcif_hex_subme5_final", "pslice_cif_umh_subme7_final", "pslice_cavlc_cif_umh_subme7_final"]
+
+
+@pytest.mark.parametrize("name", FINAL_SLICES)
+def test_final_mvs_are_what_a_decoder_reads(pc, name):
+    """SURVEY 8f rank 1 chained to the GPU: pass 1 + embedding + pass 2 on the GPU from the fixture's pictures; the slice the
+    REFERENCE's entropy coder wrote for the same frame (its own second pass with the same flips) is parsed by the MV-syntax
+    extractor: types, partitions and final motion vectors agree, and the payload the GPU embedded comes back out of the parsed
+    stream's motion (decode-side BER = 0 on GPU output)."""
+    g = helpers.load(name)
+    W, H, qp = int(g["width"]), int(g["height"]), int(g["qp"])
+    cabac = int(g["cabac"])
+    p = _params(pc, W, H, int(g["me"]), int(g["subme"]), int(g["inter"]) & 0x30, int(g["mv_range"]), cabac=cabac)
+    enc = pc.Encoder(p)
+    enc.set_ref(g["ref_y"], g["ref_u"], g["ref_v"]); enc.upload_fenc(g["fenc_y"], g["fenc_u"], g["fenc_v"])
+    mbs, _ = enc.analyse_pframe(qp, embed=1)
+    emb = enc.embed_pframe(0.5)
+    fin, _, _ = enc.pass2_pframe()
+    rbsp, _, _ = pc.nal_to_rbsp(g["nal"].tobytes())
+    got = pc.parse_pslice_at(rbsp, int(g["nal_hdr_bits"]), W // 16, H // 16, qp if cabac else None)
+    assert np.array_equal(got["i_type"], mbs["i_type"]) and np.array_equal(got["i_partition"], mbs["i_partition"])
+    bad = np.argwhere((got["mv"] != fin["mv"]).reshape(len(fin), -1).any(1)).ravel()
+    assert len(bad) == 0, f"final motion differs from the stream's at macroblocks {bad[:8].tolist()}"
+    got["used"] = mbs["used"]
+    lsb = helpers.carrier_lsbs(got)
+    assert len(lsb) == emb["n"] == int(g["n"]) and np.array_equal(lsb, emb["stego"])
+    msg = pc.stc_extract(lsb, emb["m"])
+    assert np.array_equal(msg, emb["message"]) and np.array_equal(msg, g["message"]), "decode-side BER != 0"
+    enc.close()
+
+
+def test_mvsyntax_extractor_rows_on_the_gpu_box(pc):
+    """the extractor's own suite (host code of the same library; tests/test_mvsyntax.py, CPU suite) once more where the GPU tests
+    run, so that the row is covered by the run that records which native code was loaded"""
+    import test_mvsyntax as tm
+    for name in tm.FIXTURES:
+        tm.test_parser_reads_back_what_the_reference_coded(name)
+        tm.test_slice_data_inside_a_nal_unit_behind_a_header(name)
+        if name.endswith("_final"):
+            tm.test_payload_comes_back_out_of_the_stream(name)
+    tm.test_damaged_streams_are_reported()
+    tm.test_skip_run_beyond_the_picture_is_reported()
+
+
+def test_batch_survives_a_closed_context(pc):
+    """a context closed before its batch: every batch entry point reports it (PCAMV_EINVAL), none dereferences the dead slot"""
+    import ctypes as C
+    W, H = 176, 144
+    encs = [pc.Encoder(_params(pc, W, H, 1, 5, 0x10, 64)) for _ in range(3)]
+    batch = pc.Batch(encs)
+    encs[1].close()
+    assert batch.dominant_kernel() == "k_analyse_flow"
+    batch.kernel_time(reset=True)
+    with pytest.raises(pc.PcamvError, match="closed"):
+        batch.step(26, 0.5, 0)
+    buf = np.zeros(3 * 99 * 236, np.uint8)
+    with pytest.raises(pc.PcamvError, match="closed"):
+        batch.copy_results_async(buf.ctypes.data, 99 * 236)
+    batch.close()
+    encs[0].close(); encs[2].close()
+
+
+@pytest.mark.parametrize("inst", ["hi", "spec4"])
+def test_bench_regime_matches_oracle(pc, monkeypatch, inst):
+    """The regime bench.py times, against the oracle: --me umh --subme 7 with CABAC (analyse.c:2117-2186, rdo.c:139-171), the
+    4-waves-per-SIMD build of the RD kernel ("hi": the default run's 4096 chains; "spec4": the speculative one its g_sweep / clip_600
+    blocks run at 705..3584 chains), eight per-XCD queues (40 closed GOPs = five chains per queue), fewer waves than chains
+    (12: a wave that finishes a macroblock takes whatever chain's next one is ready, queues without a wave of their own are drained
+    by work stealing), the second pass in tasks of 8 macroblocks; three closed-loop steps; of EVERY GOP the records, the context states
+    after every macroblock, the embedding vectors, the deblocked planes and the payload back out of the final motion vectors."""
+    monkeypatch.setenv("PCAMV_RD_INSTANCE", inst)
+    monkeypatch.setenv("PCAMV_PASS2_UNIT", "8")
+    monkeypatch.setenv("PCAMV_FLOW_WAVES", "12")
+    assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 40, 3, 171, hashes=True) > 0
+
+
 @pytest.mark.parametrize("waves", [1, 2, 5])
 def test_speculative_chain_with_few_waves(pc, monkeypatch, waves):
     """the speculative raster chain when waves are scarcer than the work it exposes (1 wave: every macroblock finds its predecessor
