@@ -636,6 +636,7 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_, int part_)
     }
     PROF_ADD(25, t_2);
     const unsigned long long t_3 = PROF_T();
+#ifdef PCAMV_RESIDUAL_V1
     /* ---- 3 */
     for (int pass = 0; pass < 3; pass++) {
         const unsigned catm = pass == 0 ? 0xffffu : pass == 1 ? 0x3000000u : 0xff0000u;
@@ -690,6 +691,126 @@ PCAMV_RESIDUAL_FN CabBits cab_residual_walk(MBLocal *L, int commit_, int part_)
         if (lane < cnt - 1) { D[sig_off + lane] = (uint8_t)sigS; D[last_off + lane] = (uint8_t)lastS; }
         if (lane < 10) D[lvl_off + lane] = (uint8_t)lvlS;
     }
+#else
+    /* ---- 3 (round 3): nothing per level or per block on the scalar side any more.
+     * 3a. Every block with levels (its own lane) describes, in ten words, what it contributes to each context, in closed form: with
+     *     n levels, `last` the highest position, h the highest position of a level above 1 and t the number of levels above h
+     *     (= n when there is none above 1), the level chain from the last level down visits node min(r, 3) for its r-th level while
+     *     r <= t, then node >= 4 -- so coeff_abs_level_minus1 contexts 1..3 see at most one decision of the block (level r = 0 / 1 / 2:
+     *     bin r == t), context 4 the levels 3..min(t, n - 1) (zeros, the last a one when it is level t), context 0 every level below
+     *     h (bin = above 1), and the s-th level above 1 puts its unary run on context 5 + min(s, 4); the significance map is the
+     *     mask of positions <= last with the non-zero mask as its bins, last_significant the non-zero mask with bit `last` as bins.
+     *     Row (LDS): [0] P | counts of contexts 1..3 << 16, [1] nz | their bins << 16, [2] 1 << last, [3] context 0, [4] context 4,
+     *     [5..8] contexts 5..8 (bins | count << 26), [9] 0.
+     * 3b. One lane per context (significance 15 / 3 / 14, contexts 1..3, last, contexts 0 and 4..9: 40 lanes for luma, 16 for the
+     *     chroma DCs beside them, 38 for chroma AC in a second round) appends its bins of block after block to its queue -- one
+     *     or two LDS reads and a dozen VALU instructions per block for ALL contexts -- and the queues are walked against the table
+     *     once per round (cabq_resolve: the chain is the longest queue).  Only a block's fifth and further levels above 1 (context
+     *     9, runs of up to 14 bins each) are pushed from the scalar side as before. */
+    uint32_t *ROW = (uint32_t *)L->cxy;                 /* cxy[64] + ccost[192]: idle outside a list evaluation; rows of blocks 0..23 */
+    uint32_t *ROWDC = (uint32_t *)L->red;               /* rows of the two chroma DC blocks */
+    const bool has_levels = lane < 26 && ((flagm >> lane) & 1u) != 0;       /* (a shift by the lane number wraps at 32) */
+    if (has_levels) {
+        const unsigned nz = nzm;
+        const int n = __builtin_popcount(nz), last = 31 - __builtin_clz(nz);
+        const int h = gt1 ? 31 - __builtin_clz(gt1) : -1;
+        const int t = gt1 ? __builtin_popcount(nz >> (h + 1)) : n;
+        const unsigned c2 = (n >= 2 && t >= 1) ? 1u : 0u, c3 = (n >= 3 && t >= 2) ? 1u : 0u;
+        const unsigned b1 = t == 0 ? 1u : 0u, b2 = (c2 && t == 1) ? 1u : 0u, b3 = (c3 && t == 2) ? 1u : 0u;
+        const int cnt4 = imax(imin(t, n - 1) - 2, 0);
+        const unsigned bits4 = (t < n && t >= 3) ? 1u << (cnt4 - 1) : 0u;
+        unsigned bits0 = 0, w5 = 0, w6 = 0, w7 = 0, w8 = 0;
+        int r0 = 0, sidx = 0, esc = 0;
+        bool first = true;
+        for (unsigned mm = gt1 ? nz & ((2u << h) - 1u) : 0u; mm;) {
+            const int i = 31 - __builtin_clz(mm);
+            mm &= ~(1u << i);
+            const unsigned g = (gt1 >> i) & 1u;
+            if (!first) { bits0 |= g << r0; r0++; }
+            first = false;
+            if (g) {
+                int a = (int)(((i < 8 ? nib0 : nib1) >> (4 * (i & 7))) & 15u);
+                if (a == 15) {          /* 15 or more: the exact magnitude (escape suffix) from the block's levels */
+                    const int16_t *l = lane < 16 ? L->coef[lane] : lane < 24 ? L->coef[lane] + 1 : L->cdc[lane - 24];
+                    a = iabs((int)l[i]);
+                }
+                const int am1 = a - 1, prefix = imin(am1, 14), ones = prefix - 1, z = prefix < 14 ? 1 : 0;
+                if (prefix >= 14) esc += (2 * (31 - __builtin_clz((unsigned)(am1 - 14) + 1u)) + 1) << 8;       /* size_ue */
+                const unsigned w = ((1u << ones) - 1u) | (unsigned)(ones + z) << 26;
+                w5 = sidx == 0 ? w : w5; w6 = sidx == 1 ? w : w6; w7 = sidx == 2 ? w : w7; w8 = sidx == 3 ? w : w8;
+                sidx++;
+            }
+        }
+        bits += 256 * n + esc;                           /* signs, escape suffixes */
+        PROF_CNT(30, n);
+        uint32_t *row = lane < 24 ? ROW + 10 * lane : ROWDC + 10 * (lane - 24);
+        row[0] = ((2u << last) - 1u) | (1u | c2 << 1 | c3 << 2) << 16;
+        row[1] = nz | (b1 | b2 << 1 | b3 << 2) << 16;
+        row[2] = 1u << last;
+        row[3] = bits0 | (unsigned)r0 << 26;
+        row[4] = bits4 | (unsigned)cnt4 << 26;
+        row[5] = w5; row[6] = w6; row[7] = w7; row[8] = w8; row[9] = 0u;
+    }
+    const unsigned manym = (unsigned)__ballot(has_levels && __builtin_popcount(gt1) > 4);
+    PCAMV_WAVE_SYNC();
+    for (int round = 0; round < 2; round++) {
+        const unsigned bm0 = flagm & (round == 0 ? 0x300ffffu : 0xff0000u);
+        if (!bm0) continue;
+        /* this lane's context: group (category), place in the group */
+        const int grp = round == 0 ? (lane < 40 ? 0 : 1) : 2;                         /* 0 luma 4x4, 1 chroma DC, 2 chroma AC */
+        const int wl = grp == 1 ? lane - 40 : lane;
+        const int ns = grp == 0 ? 15 : grp == 1 ? 3 : 14;
+        const int sig_off = grp == 0 ? 134 : grp == 1 ? 149 : 152, last_off = grp == 0 ? 195 : grp == 1 ? 210 : 213, lvl_off = grp == 0 ? 247 : grp == 1 ? 257 : 266;
+        const bool k_sig = wl < ns, k_one = !k_sig && wl < ns + 3, k_last = wl >= ns + 3 && wl < 2 * ns + 3, k_wide = wl >= 2 * ns + 3 && wl < 2 * ns + 10;
+        const bool live = k_sig || k_one || k_last || k_wide;
+        const int j = wl - 2 * ns - 3;                                                   /* wide: 0 = context 0, 1..6 = contexts 4..9 */
+        const int colC = k_last ? 1 : k_wide ? 3 + j : 0, colB = k_last ? 2 : k_wide ? 3 + j : 1;
+        const int sh = k_sig ? wl : k_one ? 16 + (wl - ns) : k_last ? wl - ns - 3 : 0;
+        const int ctx = k_sig ? sig_off + wl : k_one ? lvl_off + 1 + (wl - ns) : k_last ? last_off + (wl - ns - 3) : lvl_off + (j == 0 ? 0 : 3 + j);
+        const unsigned mycat = grp == 0 ? 0xffffu : grp == 1 ? 0x3000000u : 0xff0000u;
+        const uint32_t *base = grp == 1 ? ROWDC - 240 : ROW;                              /* row of block b = base + 10 b */
+        int st = live ? S[ctx] : 0;
+        unsigned long long q = 0; int qn = 0;
+        unsigned m = bm0;
+        int b = __builtin_ctz(m);
+        uint32_t cw = live ? base[10 * b + colC] : 0u, bw = live ? base[10 * b + colB] : 0u;
+        while (m) {
+            m &= m - 1;
+            const int bn = m ? __builtin_ctz(m) : b;
+            const uint32_t cw_n = live ? base[10 * bn + colC] : 0u, bw_n = live ? base[10 * bn + colB] : 0u;      /* the next block's words while this one's are used */
+            if (live && ((mycat >> b) & 1u)) {
+                const uint32_t xc = cw >> sh, xb = bw >> sh;
+                const int cnt = k_wide ? (int)(xc >> 26) : (int)(xc & 1u);
+                const unsigned bins = k_wide ? xc & 0x3ffffffu : xb & 1u;
+                q |= (unsigned long long)bins << qn;
+                qn += cnt;
+            }
+            if ((manym >> b) & 1u) {          /* the block's fifth and further levels above 1: context 9, from the scalar side */
+                const unsigned g1 = (unsigned)__builtin_amdgcn_readlane((int)gt1, b);
+                const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nib0, b), n1 = (unsigned)__builtin_amdgcn_readlane((int)nib1, b);
+                int sidx = 0;
+                for (unsigned mm = g1; mm; sidx++) {
+                    const int i = 31 - __builtin_clz(mm);
+                    mm &= ~(1u << i);
+                    if (sidx < 4) continue;
+                    int a = (int)(((i < 8 ? n0 : n1) >> (4 * (i & 7))) & 15u);
+                    if (a == 15) {
+                        const int16_t *l = b < 16 ? L->coef[b] : b < 24 ? L->coef[b] + 1 : L->cdc[b - 24];
+                        a = rfl(iabs((int)l[i]));
+                    }
+                    const int prefix = imin(a - 1, 14);
+                    if (__builtin_amdgcn_ballot_w64(qn > 64 - 16)) bits += cabq_resolve(T, st, q, qn);
+                    cabq_push_run(q, qn, b >= 24 ? 55 : round == 0 ? 39 : 37, prefix - 1, prefix < 14);      /* the lane of the category's context 9 */
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(qn > 64 - 26)) bits += cabq_resolve(T, st, q, qn);     /* no queue may pass 64 bins */
+            b = bn; cw = cw_n; bw = bw_n;
+        }
+        bits += cabq_resolve(T, st, q, qn);
+        if (live) D[ctx] = (uint8_t)st;
+    }
+    (void)sbits;
+#endif
     PROF_ADD(26, t_3);
     out.vbits = bits; out.bits = sbits;
     return out;
