@@ -9,6 +9,7 @@ mv /tmp/pobj/$u.o.0.hipv4-amdgcn-amd-amdhsa--gfx950 $u.co; rm -f /tmp/pobj/$u.o.
 /opt/rocm/lib/llvm/bin/llvm-objdump -d $u.co > $u.s
 a=$(grep -n "<$k" $u.s | head -1 | cut -d: -f1)
 b=$(awk -v a=$a 'NR>a && /^[0-9a-f]+ <_Z/{print NR; exit}' $u.s)
+[ -z "$b" ] && b=$(( $(wc -l < $u.s) + 1 ))          # the kernel is the last symbol of the code object
 sed -n "${a},$((b-1))p" $u.s > ${u}_k.s
 for p in global_load flat_load scratch_load scratch_store s_waitcnt v_readlane v_mul_lo_u32 s_cbranch "^\s*v_" "^\s*s_"; do echo "$p $(grep -c "$p" ${u}_k.s)"; done
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $u.co | grep "\.name:\|vgpr_count\|vgpr_spill\|sgpr_spill\|group_segment_fixed" | paste - - - - - | grep "$k" | sed 's/ \+/ /g'

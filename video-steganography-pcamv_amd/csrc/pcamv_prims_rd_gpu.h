@@ -418,20 +418,62 @@ __device__ __forceinline__ void had_lane_sums(const uint8_t *buf, int lane, int 
     for (int k = 0; k < 16; k++) { a4 += iabs(t[k]); a8 += iabs(quad_had2x2(t[k], lane & 3)); }
     *s4 = a4; *dc = t[0]; *s8 = a8;
 }
+/* The same energies with the whole wave at work: lane = 4 * block (x264 order) + row of the block, so a block is a quad of
+ * lanes and an 8x8 a row of 16.  A lane transforms its row of four pixels (packed 16-bit: (p0 + p1, p2 + p3), (p0 - p1, p2 - p3);
+ * the last butterfly of the horizontal transform is never made: sum |x + y| + |x - y| = 2 max(|x|, |y|)), the vertical transform
+ * runs across the quad and the 2x2 of the 8x8 across the row of 16 (butterflies as partner + sign * own: the sign of a lane's
+ * whole vector is free, every sum taken is of magnitudes).  Returns the lane's shares of half the sum of |4x4 coefficients|,
+ * half the sum of |8x8 coefficients| and the pixel sum of its row.  Values stay below 8160 * 2: 16-bit is exact. */
+__device__ __forceinline__ v2s had_bfly(v2s x, int partner, bool minus)
+{
+    const v2s one = {1, 1}, mone = {-1, -1};
+    return x * (minus ? mone : one) + as_v2s((uint32_t)partner);
+}
+__device__ __forceinline__ int had_pairmax(v2s s, v2s d)
+{
+    const v2s z = {0, 0};
+    const v2s as = __builtin_elementwise_max(s, z - s), ad = __builtin_elementwise_max(d, z - d);
+    const v2s m = __builtin_elementwise_max(as, __builtin_shufflevector(as, as, 1, 0)) + __builtin_elementwise_max(ad, __builtin_shufflevector(ad, ad, 1, 0));
+    return (int)(as_u32(m) & 0xffffu);
+}
+__device__ __forceinline__ void had_row_shares(const uint8_t *buf, int lane, int *h4, int *h8, int *dc)
+{
+    const int b = lane >> 2;
+    const uint32_t row = lds4(buf + (4 * blk_y_of(b) + (lane & 3)) * 16 + 4 * blk_x_of(b));
+    const v2s A = as_v2s(__builtin_amdgcn_perm(0u, row, 0x0c020c00u)), B = as_v2s(__builtin_amdgcn_perm(0u, row, 0x0c030c01u));      /* (p0, p2), (p1, p3) */
+    v2s S = A + B, D = A - B;
+    S = had_bfly(S, dpp_qp1((int)as_u32(S)), lane & 1); D = had_bfly(D, dpp_qp1((int)as_u32(D)), lane & 1);
+    S = had_bfly(S, dpp_qp2((int)as_u32(S)), lane & 2); D = had_bfly(D, dpp_qp2((int)as_u32(D)), lane & 2);
+    *h4 = had_pairmax(S, D);
+    *dc = (int)__builtin_amdgcn_sad_u8(row, 0u, 0u);
+    /* lane ^ 4, lane ^ 8 inside the row of 16: two row shifts, each written to the banks (quads) it is right for */
+    {
+        int ps = __builtin_amdgcn_update_dpp(0, (int)as_u32(S), 0x104, 0xf, 0x5, false); ps = __builtin_amdgcn_update_dpp(ps, (int)as_u32(S), 0x114, 0xf, 0xa, false);
+        int pd = __builtin_amdgcn_update_dpp(0, (int)as_u32(D), 0x104, 0xf, 0x5, false); pd = __builtin_amdgcn_update_dpp(pd, (int)as_u32(D), 0x114, 0xf, 0xa, false);
+        S = had_bfly(S, ps, lane & 4); D = had_bfly(D, pd, lane & 4);
+    }
+    {
+        int ps = __builtin_amdgcn_update_dpp(0, (int)as_u32(S), 0x108, 0xf, 0x3, false); ps = __builtin_amdgcn_update_dpp(ps, (int)as_u32(S), 0x118, 0xf, 0xc, false);
+        int pd = __builtin_amdgcn_update_dpp(0, (int)as_u32(D), 0x108, 0xf, 0x3, false); pd = __builtin_amdgcn_update_dpp(pd, (int)as_u32(D), 0x118, 0xf, 0xc, false);
+        S = had_bfly(S, ps, lane & 8); D = had_bfly(D, pd, lane & 8);
+    }
+    *h8 = had_pairmax(S, D);
+}
 __device__ __forceinline__ void prim_fenc_complexity(const FrameDev &F, MBLocal *L)      /* x264_mb_cache_fenc_satd */
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
     int satd = 0, sa8d = 0;
     if (F.psy_rd) {
-        int s4, dc, s8;
-        had_lane_sums(L->fenc, lane, &s4, &dc, &s8);
-        int q8 = s8 + dpp_qp1(s8); q8 += dpp_qp2(q8);
-        int qd = dc + dpp_qp1(dc); qd += dpp_qp2(qd);
-        int a = lane < 16 ? (s4 >> 1) - (dc >> 1) : 0;
-        int b = (lane < 16 && (lane & 3) == 0) ? ((q8 + 2) >> 2) - (qd >> 2) : 0;
-        a = group_sum(a, 16); b = group_sum(b, 16);
-        satd = __builtin_amdgcn_readlane(a, 0); sa8d = __builtin_amdgcn_readlane(b, 0);
+        int h4, h8, dc;
+        had_row_shares(L->fenc, lane, &h4, &h8, &dc);
+        /* per 4x4: satd - (dc >> 1) with satd = sum |coefficients| >> 1; per 8x8: ((sum |coefficients| + 2) >> 2) - (dc >> 2) */
+        int b4 = h4 + dpp_qp1(h4); b4 += dpp_qp2(b4);
+        int d4 = dc + dpp_qp1(dc); d4 += dpp_qp2(d4);
+        const int b8 = group_sum(h8, 16), d8 = group_sum(dc, 16);
+        int a = (lane & 3) == 0 ? b4 - (d4 >> 1) : 0;
+        int b = (lane & 15) == 0 ? ((2 * b8 + 2) >> 2) - (d8 >> 2) : 0;
+        satd = wave_sum_all(a); sa8d = wave_sum_all(b);
     }
     if (lane == 0) { L->fenc_satd_sum = satd; L->fenc_sa8d_sum = sa8d; }
     PCAMV_WAVE_SYNC();
@@ -440,29 +482,31 @@ __device__ __forceinline__ void prim_fenc_complexity(const FrameDev &F, MBLocal 
  * (low word of the reference's result) and of the 8x8 transforms (high word) */
 __device__ __forceinline__ void prim_hadamard_ac16(const uint8_t *buf, int lane, int *sum4, int *sum8)
 {
-    int s4, dc, s8;
-    had_lane_sums(buf, lane, &s4, &dc, &s8);
-    if (lane >= 16) { s4 = 0; dc = 0; s8 = 0; }
-    s4 = group_sum(s4, 16); dc = group_sum(dc, 16); s8 = group_sum(s8, 16);
-    *sum4 = (__builtin_amdgcn_readlane(s4, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 1;
-    *sum8 = (__builtin_amdgcn_readlane(s8, 0) - __builtin_amdgcn_readlane(dc, 0)) >> 2;
+    int h4, h8, dc;
+    had_row_shares(buf, lane, &h4, &h8, &dc);
+    const int t4 = wave_sum_all(h4), t8 = wave_sum_all(h8), td = wave_sum_all(dc);
+    *sum4 = (2 * t4 - td) >> 1;
+    *sum8 = (2 * t8 - td) >> 2;
 }
 /* ssd_mb (rdo.c:106-137) of the reconstruction in L->pred: SSD of luma + both chroma planes, plus for luma the psy term
- * |AC energy (4x4) difference| + |AC energy (8x8) difference| (the hadamard_ac branch: PIXEL_16x16 <= PIXEL_8x8) */
+ * |AC energy (4x4) difference| + |AC energy (8x8) difference| (the hadamard_ac branch: PIXEL_16x16 <= PIXEL_8x8).
+ * A row of four pixels per lane (64 luma rows, then the 32 chroma rows on half the wave): sum (e - p)^2 = e.e + p.p - 2 e.p,
+ * three byte dot products */
 __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
 {
     PCAMV_WAVE_SYNC();
     const int lane = LANE();
-    int v = 0;
-    if (lane < 24) {
-        const int ch = (lane - 16) >> 2, ci = (lane - 16) & 3;
-        const int px = lane < 16 ? 4 * blk_x_of(lane) : ch * 8 + (ci & 1) * 4, py = lane < 16 ? 4 * blk_y_of(lane) : 16 + (ci >> 1) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t e = lds4(L->fenc + (py + k) * 16 + px), p = lds4(L->pred + (py + k) * 16 + px);
-#pragma unroll
-            for (int x = 0; x < 4; x++) { const int dd = (int)((e >> (8 * x)) & 255) - (int)((p >> (8 * x)) & 255); v += mul24s(dd, dd); }
-        }
+    const int b = lane >> 2, rr = lane & 3;
+    int v;
+    {
+        const int o = (4 * blk_y_of(b) + rr) * 16 + 4 * blk_x_of(b);
+        const uint32_t e = lds4(L->fenc + o), p = lds4(L->pred + o);
+        v = (int)__builtin_amdgcn_udot4(p, p, __builtin_amdgcn_udot4(e, e, 0u, false), false) - 2 * (int)__builtin_amdgcn_udot4(e, p, 0u, false);
+    }
+    if (lane < 32) {
+        const int o = (16 + (b & 2) * 2 + rr) * 16 + (b >> 2) * 8 + (b & 1) * 4;          /* b = 4 * plane + block of the plane */
+        const uint32_t e = lds4(L->fenc + o), p = lds4(L->pred + o);
+        v += (int)__builtin_amdgcn_udot4(p, p, __builtin_amdgcn_udot4(e, e, 0u, false), false) - 2 * (int)__builtin_amdgcn_udot4(e, p, 0u, false);
     }
     int ssd = wave_sum_all(v);
     if (F.psy_rd) {
