@@ -134,6 +134,7 @@ __device__ __forceinline__ int prim_mv_cost(const FrameDev &F, int d)
  * (pixel coordinates, strides, quantiser factors, bilinear weights, levels) the 24-bit forms give the same low 32 bits at full rate */
 __device__ __forceinline__ uint32_t mul24u(uint32_t a, uint32_t b) { return __umul24(a, b); }
 __device__ __forceinline__ int mul24s(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ int mad24s(int a, int b, int c) { return __mul24(a, b) + c; }
 __device__ __forceinline__ uint32_t lsw_x(uint32_t x, uint32_t lskip) { return mul24u(mul24u(x, 18725u) >> 19, lskip) + x; }
 __device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
 __device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
@@ -735,42 +736,39 @@ __device__ __forceinline__ void quant_score_dequant(const FrameDev &F, bool is_l
     const int mf0 = is_l ? F.q_mf[0][0] : F.q_mf[1][0], mf1 = is_l ? F.q_mf[0][1] : F.q_mf[1][1], mf2 = is_l ? F.q_mf[0][2] : F.q_mf[1][2];
     const int bs0 = is_l ? F.q_bias[0][0] : F.q_bias[1][0], bs1 = is_l ? F.q_bias[0][1] : F.q_bias[1][1], bs2 = is_l ? F.q_bias[0][2] : F.q_bias[1][2];
     const int dq0 = is_l ? F.dq_mf[0] : F.dq_mf_c[0], dq1 = is_l ? F.dq_mf[1] : F.dq_mf_c[1], dq2 = is_l ? F.dq_mf[2] : F.dq_mf_c[2];
-    /* quantise; build the non-zero mask in zigzag order and the "some |level| > 1" flag on the way */
-    unsigned zm = 0; int big = 0;
+    /* quantise (quant.c:33-48: c > 0 ? (bias + c) * mf >> 16 : -((bias - c) * mf >> 16)) as ONE signed multiply-add and an arithmetic
+     * shift per coefficient: with bm = bias * mf (< 2^16, so c = 0 stays 0) the positive arm is (c * mf + bm) >> 16, and the negative one,
+     * -floor(x / 2^16) with x = |c| * mf + bm, is (c * mf - bm + 65535) >> 16; |c| < 2^14, mf < 2^16.  The non-zero mask in zigzag order
+     * and the "some |level| > 1" flag come from the levels afterwards (maximum / minimum of all sixteen). */
+    const int bm0 = (int)mul24u((uint32_t)bs0, (uint32_t)mf0), bm1 = (int)mul24u((uint32_t)bs1, (uint32_t)mf1), bm2 = (int)mul24u((uint32_t)bs2, (uint32_t)mf2);
+    unsigned zm = 0; int mx = 0, mn = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         constexpr int zzinv[16] = {0, 2, 3, 9, 1, 4, 8, 10, 5, 7, 11, 14, 6, 12, 13, 15};   /* raster index -> scan position (inverse of the zigzag) */
-        const int cls = (i & 1) + ((i >> 2) & 1), mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bias = cls == 0 ? bs0 : cls == 1 ? bs1 : bs2;
-        int c = d[i];
-        /* quant.c:33-48: c > 0 ? (bias + c) * mf >> 16 : -((bias - c) * mf >> 16), without the branch the compiler made of it (two arms
-         * per coefficient, each re-reading a dozen parked scalars); bias * mf < 2^16, so c = 0 stays 0; bias + |c| < 2^17, mf < 2^16 */
-        const int qa = (int)(mul24u((uint32_t)(bias + iabs(c)), (uint32_t)mf) >> 16);
-        c = c < 0 ? -qa : qa;
-        d[i] = (int16_t)c;
-        zm |= (unsigned)(c != 0) << zzinv[i];
-        big |= (unsigned)(c + 1) > 2u;
+        const int cls = (i & 1) + ((i >> 2) & 1), mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bm = cls == 0 ? bm0 : cls == 1 ? bm1 : bm2;
+        const int c = d[i];
+        const int q = mad24s(c, mf, c < 0 ? 65535 - bm : bm) >> 16;
+        d[i] = (int16_t)q;
+        zm |= q != 0 ? 1u << zzinv[i] : 0u;
+        mx = imax(mx, q); mn = imin(mn, q);
     }
+    const int big = mx > 1 || mn < -1;
     const int nz = zm != 0;
     if (lv_out && nz) {       /* the quantised levels in scan order (h->dct.luma4x4), for the entropy coder's size walk */
         constexpr int zz[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
 #pragma unroll
         for (int k = 0; k < 16; k += 2) *(uint32_t *)(lv_out + k) = (uint32_t)(uint16_t)d[zz[k]] | (uint32_t)(uint16_t)d[zz[k + 1]] << 16;
     }
-    /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC
-     * ones for chroma): 9 as soon as a level exceeds 1, else the run-length table summed over the
-     * non-zero levels, walked from the top of the mask */
+    /* x264_decimate_score (quant.c:203-239) on the zigzag scan (16 coefficients for luma, the 15 AC ones for chroma): 9 as soon as a
+     * level exceeds 1, else the table {3, 2, 2, 1, 1, 1, 0, ..}[run of zeros below it] summed over the non-zero levels.  Without a
+     * loop: the table is (run < 1) + (run < 3) + (run < 6), and "the run below position p is shorter than k" is "a level sits in one of
+     * the k positions below p" -- with a virtual level just below the scan's first position (bit 0 of z) that is bit p of
+     * z << 1 | .. | z << k, so each of the three terms is one population count. */
     int score = 0;
     if (nz) {
-        if (big) score = 9;
-        else {
-            unsigned m = zm; const int lo = is_l ? 0 : 1;
-            while (m) {
-                int pp = 31 - __builtin_clz(m);
-                m &= ~(1u << pp);
-                int pq = m ? 31 - __builtin_clz(m) : lo - 1;
-                score += (0x56Bu >> (2 * (pp - pq - 1))) & 3u;      /* decimate table[run] */
-            }
-        }
+        const unsigned zr = is_l ? zm << 1 : zm, z = zr | 1u;           /* (chroma: position 0, the DC, is never set -- it is the virtual level) */
+        const unsigned s1 = z << 1, s3 = s1 | s1 << 1 | z << 3, s6 = s3 | s3 << 3;
+        score = big ? 9 : __builtin_popcount(zr & s1) + __builtin_popcount(zr & s3) + __builtin_popcount(zr & s6);
         const int qbits = qp / 6 - 4;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
