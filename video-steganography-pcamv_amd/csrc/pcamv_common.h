@@ -97,6 +97,7 @@ struct FrameDev {
     const uint8_t *cabac_init;     /* [PCAMV_CHAIN_BYTES] the same at the slice start: states for this QP (H.264 9.3.1.1, cabac_init_idc 0), zeros */
     const uint32_t *cabac_tab;     /* [256] per (state, bin): 8.8 fixed-point bits << 8 | next state */
     uint32_t *dbg_hash;            /* diagnostics: [n_mb] FNV-1a of the context states after each macroblock, or NULL */
+    int rec_is_pass1;              /* pass 2: rec / nnz still hold what this frame's first pass left (nothing has filtered them yet) */
 };
 
 /* Small lookup tables live in registers as packed constants: a table in memory costs one global

@@ -66,6 +66,7 @@ struct pcamv_ctx {
     int cap;
     int *d_trace;
     uint16_t *d_nnz; int *d_car_base; int8_t *d_flip_user;     /* pass 2 */
+    int rec_pristine;          /* d_rec / d_nnz hold the first pass' reconstruction of the frame last analysed (no second pass has run over it) */
     /* --subme >= 6 */
     uint8_t *d_nb_nz, *d_cabac, *d_cabac_init[52]; int16_t *d_nb_cbp, *d_nb_mvd; uint32_t *d_cabac_tab, *d_dbg_hash;
     char err[256];
@@ -519,6 +520,9 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
             c->F.prev_mv = wr ? c->d_mv : c->d_mv_b; c->F.prev_ref = wr ? c->d_ref8 : c->d_ref8_b;
         }
         if (what & 2) c->last_field = c->F.mv == c->d_mv_b;
+        if (what & 2) c->rec_pristine = 1;         /* the analysis leaves the first pass' reconstruction + non-zero flags in rec / nnz ... */
+        c->F.rec_is_pass1 = (what & 8) ? c->rec_pristine : 0;
+        if (what & 8) c->rec_pristine = 0;         /* ... until a second pass has filtered the picture in place */
     }
     const FrameDev *dF; const EmbedDev *dE; int slot;
     int rc = batch_push_descs(b, st, &dF, &dE, &slot);
@@ -747,6 +751,8 @@ extern "C" int pcamv_gpu_pass2_pframe(pcamv_ctx_t *c, const uint8_t *flips, int 
     /* pass-2 reconstruction first (for callers that want it before the loop filter), then the filter */
     pcamv_batch *b = c->self;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->F.rec_is_pass1 = c->rec_pristine;
+    c->rec_pristine = 0;
     {   /* pass 2 only */
         const FrameDev *dF; const EmbedDev *dE; int slot;
         int rc = batch_push_descs(b, c->stream, &dF, &dE, &slot);

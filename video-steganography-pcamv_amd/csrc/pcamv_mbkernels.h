@@ -41,6 +41,7 @@ PCAMV_DEV void mbk_search_finish(const FrameDev &F, MBLocal *L, Analysis *a, int
 #else
         prim_store_rec(F, L, true);
 #endif
+        if (PCAMV_LANE0 && F.nnz) F.nnz[L->mb_xy] = (uint16_t)L->nnz_mask;      /* with the pixels: what pass 2 takes over for a macroblock the embedding leaves alone */
         entropy_commit(F, L, kept);
         PROF_ADD(22, t_c);
     }
@@ -160,6 +161,7 @@ PCAMV_DEV int mbk_recon(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int 
     }
     mb_encode(F, L);
     prim_store_rec(F, L);
+    if (PCAMV_LANE0 && F.nnz) F.nnz[xy] = (uint16_t)L->nnz_mask;
     PROF_ADD(10, t_e);
     return n;
 }
@@ -220,9 +222,11 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
     L->i_type = r->i_type; L->i_partition = r->i_partition;
     for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
     cache_ref_set(L, 0, 0, 4, 4, 0);
+    int same;
     if (L->i_type == PCAMV_P_SKIP) {
         L->i_partition = PCAMV_D_16x16;
         cache_mv_set(L, 0, 0, 4, 4, L->pskip_mv[0], L->pskip_mv[1]);
+        same = L->pskip_mv[0] == r->pskip_mv[0] && L->pskip_mv[1] == r->pskip_mv[1];
     } else {
         int *slots = L->slots;
         const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, r->used, slots);
@@ -238,13 +242,27 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
             L->cmv[scan8_of(i)][1] = flipped ? r->mv_stego[s][1] : r->mv[i][1];
         }
         PCAMV_WAVE_SYNC();
+        same = 1;
+        for (int j = 0; j < n; j++) if (L->cxy[j]) same = 0;
     }
-    mb_encode(F, L);
+    /* A macroblock whose motion is what the first pass decided -- no carrier of it flipped; skipped with the same skip prediction --
+     * reconstructs to what the first pass stored (same type, motion, source, reference and quantiser): pixels and non-zero flags
+     * are taken from there instead of being made again.  (~7 of 8 macroblocks at half a bit per carrier.) */
+    if (same && F.rec_is_pass1) {
 #ifdef PCAMV_HOST_EMU
-    prim_store_rec(F, L);
+        L->nnz_mask = F.nnz[xy];
 #else
-    if (store_rec) prim_store_rec(F, L, true);
+        L->nnz_mask = rfl((int)F.nnz[xy]);
+        prim_load_rec(F, L);
 #endif
+    } else {
+        mb_encode(F, L);
+#ifdef PCAMV_HOST_EMU
+        prim_store_rec(F, L);
+#else
+        if (store_rec) prim_store_rec(F, L, true);
+#endif
+    }
     /* final motion, type and non-zero flags: read by the neighbours' skip prediction and loop filter in the same
      * launch, so stored write-through like the search's hand-off */
     const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w, b4 = 4 * (mb_y * s4 + mb_x), b8 = 2 * (mb_y * s8 + mb_x);
@@ -266,5 +284,6 @@ PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
     update_cache(L, a);
     mb_encode(F, L);
     prim_store_rec(F, L);
+    if (PCAMV_LANE0 && F.nnz) F.nnz[xy] = (uint16_t)L->nnz_mask;
 }
 #endif

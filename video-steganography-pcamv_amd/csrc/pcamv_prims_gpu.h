@@ -1079,6 +1079,20 @@ __device__ __forceinline__ void prim_store_rec(const FrameDev &F, MBLocal *L, bo
         if (wt) NB_ST32(d, v); else *d = v;
     }
 }
+/* the macroblock's reconstruction back out of the frame (pass 2 of a macroblock whose motion the embedding left alone: its first-pass
+ * reconstruction IS its final one) */
+__device__ __forceinline__ void prim_load_rec(const FrameDev &F, MBLocal *L)
+{
+    PCAMV_WAVE_SYNC();
+    const int lane = LANE();
+    { int row = lane >> 2, c4 = lane & 3;
+      sts4(L->pred + row * 16 + c4 * 4, *(const uint32_t *)(F.rec[0] + (size_t)(L->mb_y * 16 + row) * F.w + L->mb_x * 16 + c4 * 4)); }
+    if (lane < 32) {
+        int plane = lane >> 4, row = (lane & 15) >> 1, c4 = lane & 1;
+        sts4(L->pred + 256 + row * 16 + plane * 8 + c4 * 4, *(const uint32_t *)((plane ? F.rec[2] : F.rec[1]) + (size_t)(L->mb_y * 8 + row) * (F.w >> 1) + L->mb_x * 8 + c4 * 4));
+    }
+    PCAMV_WAVE_SYNC();
+}
 __device__ __forceinline__ void prim_store_mvr(const FrameDev &F, MBLocal *L, int mvx, int mvy)
 {
     if (LANE() == 0) NB_ST32(&F.mvr[2 * L->mb_xy], NB_PACK16(mvx, mvy));
