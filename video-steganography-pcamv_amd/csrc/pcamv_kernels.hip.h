@@ -598,7 +598,8 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
             for (int k = 0; k < fl.unit; k++) {
                 const int mx = fl.unit * x + k;
                 if (mx >= F.mb_w) break;
-                if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels this one reads */
+                /* (the filter of the macroblock to the left changed pixels, and its second pass stored motion, that this one reads: its
+                 * stores are waited for inside mbk_pass2, together with the load of this macroblock's record -- not before it) */
                 mbk_pass2(F, &L, mx, y, 0);
                 PCAMV_WAVE_SYNC();
                 mbk_deblock(F, Dp, mx, y, &L);          /* the unfiltered macroblock goes from LDS to LDS, not through memory */

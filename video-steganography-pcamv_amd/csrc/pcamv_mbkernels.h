@@ -217,6 +217,11 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
         if (i < (int)(sizeof(pcamv_mb_t) / 4)) ((uint32_t *)r)[i] = ((const uint32_t *)&F.rec_mb[xy])[i];
         else L->ccost[191] = F.car_base ? F.car_base[xy] : 0;
     }
+#ifndef PCAMV_HOST_EMU
+    /* several macroblocks of a row per task: the previous one's write-through stores (filtered pixels, final motion, non-zero flags)
+     * must have landed before this one's agent-scope loads of them -- waited for here, with the record's load in flight beside them */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     PCAMV_WAVE_SYNC();
     mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
     L->i_type = r->i_type; L->i_partition = r->i_partition;
