@@ -98,6 +98,7 @@ struct FrameDev {
     const uint32_t *cabac_tab;     /* [256] per (state, bin): 8.8 fixed-point bits << 8 | next state */
     uint32_t *dbg_hash;            /* diagnostics: [n_mb] FNV-1a of the context states after each macroblock, or NULL */
     int rec_is_pass1;              /* pass 2: rec / nnz still hold what this frame's first pass left (nothing has filtered them yet) */
+    const uint8_t *mbflip;         /* pass 2: [n_mb] 1 = some carrier of the macroblock is flipped in `flip` (k_mb_flips), or NULL: look at the carriers */
 };
 
 /* Small lookup tables live in registers as packed constants: a table in memory costs one global

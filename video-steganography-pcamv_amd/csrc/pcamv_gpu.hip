@@ -66,6 +66,7 @@ struct pcamv_ctx {
     int cap;
     int *d_trace;
     uint16_t *d_nnz; int *d_car_base; int8_t *d_flip_user;     /* pass 2 */
+    uint8_t *d_mbflip;         /* [n_mb] per macroblock: a carrier of it is flipped in d_flip */
     int rec_pristine;          /* d_rec / d_nnz hold the first pass' reconstruction of the frame last analysed (no second pass has run over it) */
     /* --subme >= 6 */
     uint8_t *d_nb_nz, *d_cabac, *d_cabac_init[52]; int16_t *d_nb_cbp, *d_nb_mvd; uint32_t *d_cabac_tab, *d_dbg_hash;
@@ -369,6 +370,7 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     HIPCHK(c, dalloc(&c->d_hdr, 8)); HIPCHK(c, dalloc(&c->d_rnd, 40)); HIPCHK(c, dalloc(&c->d_cols, 2 * STC_MAXW + 8)); HIPCHK(c, dalloc(&c->d_lcg, 1));
     HIPCHK(c, dalloc(&c->d_path, (size_t)c->cap * 32));
     HIPCHK(c, dalloc(&c->d_nnz, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_car_base, (size_t)F.n_mb)); HIPCHK(c, dalloc(&c->d_flip_user, (size_t)c->cap));
+    HIPCHK(c, dalloc(&c->d_mbflip, (size_t)F.n_mb)); HIPCHK(c, hipMemset(c->d_mbflip, 1, (size_t)F.n_mb));
     HIPCHK(c, hipMemset(c->d_nnz, 0, (size_t)F.n_mb * 2)); HIPCHK(c, hipMemset(c->d_car_base, 0, (size_t)F.n_mb * 4));
     HIPCHK(c, hipMemset(c->d_hdr, 0, 8 * sizeof(int)));
     if (F.b_mbrd) {
@@ -390,9 +392,10 @@ static int open_impl(pcamv_ctx *c, const pcamv_params_t *p, int device)
     F.mb_type = c->d_mb_type; F.mv = c->d_mv; F.ref8 = c->d_ref8; F.mvr = c->d_mvr;
     F.prev_mv = c->d_prev_mv; F.prev_ref = c->d_prev_ref; F.have_prev = 0;
     F.rec_mb = c->d_rec_mb; F.mvp_aux = c->d_mvp_aux;
-    F.nnz = c->d_nnz; F.car_base = c->d_car_base; F.flip = c->d_flip;
+    F.nnz = c->d_nnz; F.car_base = c->d_car_base; F.flip = c->d_flip; F.mbflip = c->d_mbflip;
     EmbedDev &E = c->E;
     E.mbs = c->d_rec_mb; E.n_mb = F.n_mb; E.cover = c->d_cover; E.stego = c->d_stego; E.message = c->d_message; E.rho = c->d_rho;
+    E.mbflip = c->d_mbflip;
     E.flip = c->d_flip; E.hdr = c->d_hdr; E.cols = c->d_cols; E.path = c->d_path; E.rnd = c->d_rnd;
     E.lcg = c->d_lcg; E.colinfo = c->d_colinfo; E.cap = c->cap; E.car_base = c->d_car_base; E.user_message = NULL; E.user_message_len = 0; E.emrate = 0;
     pcamv_ctx *one[1] = {c};
@@ -417,7 +420,7 @@ extern "C" void pcamv_gpu_close(pcamv_ctx_t *c)
     hipFree(c->d_cover); hipFree(c->d_stego); hipFree(c->d_message); hipFree(c->d_colinfo); hipFree(c->d_user_msg); hipFree(c->d_rho);
     hipFree(c->d_flip); hipFree(c->d_hdr); hipFree(c->d_rnd); hipFree(c->d_cols); hipFree(c->d_lcg); hipFree(c->d_path);
     if (c->d_trace) hipFree(c->d_trace);
-    hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user);
+    hipFree(c->d_nnz); hipFree(c->d_car_base); hipFree(c->d_flip_user); hipFree(c->d_mbflip);
     hipFree(c->d_nb_nz); hipFree(c->d_nb_cbp); hipFree(c->d_nb_mvd); hipFree(c->d_cabac); hipFree(c->d_cabac_tab); hipFree(c->d_dbg_hash);
     for (int q = 0; q < 52; q++) if (c->d_cabac_init[q]) hipFree(c->d_cabac_init[q]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -572,6 +575,7 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
         /* 2 trellis states per thread: measured 3.25 / 2.89 / 2.90 ms per 1080p frame for 1 / 2 / 4 */
         hipLaunchKernelGGL(k_stc_forward<2>, dim3(G), dim3(512), 0, st, dE);
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
+        hipLaunchKernelGGL(k_mb_flips, dim3((F.n_mb + 255) / 256, G), dim3(256), 0, st, dE);
     }
     if (what & 8) {      /* pass 2: final MVs -> reconstruction -> loop filter, same dependency as the search */
         if (b->sched_flow) {
@@ -728,7 +732,7 @@ extern "C" int pcamv_gpu_pass2_pframe(pcamv_ctx_t *c, const uint8_t *flips, int 
         if (n_flips < 0 || n_flips > c->cap) return fail(c, PCAMV_EINVAL, "n_flips");
         HIPCHK(c, hipMemset(c->d_flip_user, 0, (size_t)c->cap));
         if (n_flips) HIPCHK(c, hipMemcpy(c->d_flip_user, flips, n_flips, hipMemcpyHostToDevice));
-        c->F.flip = c->d_flip_user;
+        c->F.flip = c->d_flip_user; c->F.mbflip = nullptr;          /* a caller's map: the per-macroblock summary belongs to the embedding stage's own */
         /* carrier index of every macroblock from the record (the embedding stage may not have run) */
         pcamv_mb_t *h = (pcamv_mb_t *)malloc((size_t)c->F.n_mb * sizeof(pcamv_mb_t));
         int *base = (int *)malloc((size_t)c->F.n_mb * sizeof(int));
@@ -746,7 +750,7 @@ extern "C" int pcamv_gpu_pass2_pframe(pcamv_ctx_t *c, const uint8_t *flips, int 
         free(h); free(base);
         if (e != hipSuccess) return fail(c, PCAMV_EHIP, "pass2: %s", hipGetErrorString(e));
         if (k > n_flips) return fail(c, PCAMV_EINVAL, "flip map has %d entries, the record has %d carriers", n_flips, k);
-    } else c->F.flip = c->d_flip;
+    } else { c->F.flip = c->d_flip; c->F.mbflip = c->d_mbflip; }
     const size_t ysz = (size_t)c->F.w * c->F.h;
     /* pass-2 reconstruction first (for callers that want it before the loop filter), then the filter */
     pcamv_batch *b = c->self;
@@ -808,7 +812,7 @@ extern "C" int pcamv_gpu_batch_step(pcamv_batch_t *b, int qp, float emrate, void
         if (rc) return bfail(b, rc, "%s", c->err);
         if (!c->F.raw[0]) return bfail(b, PCAMV_EINVAL, "context %d has no reference", i);
         c->F.embed = emrate > 0; c->E.emrate = emrate; c->E.user_message = NULL; c->E.user_message_len = 0;
-        c->F.flip = c->d_flip;        /* a closed-loop step applies the flip map of its own embedding stage, never a caller's map left by pass2_pframe */
+        c->F.flip = c->d_flip; c->F.mbflip = c->d_mbflip;        /* a closed-loop step applies the flip map of its own embedding stage, never a caller's map left by pass2_pframe */
     }
     hipStream_t st = stream ? (hipStream_t)stream : b->ctx[0]->stream;
     return batch_launch(b, (emrate > 0 ? 7 : 3) | (b->closed_loop ? 8 : 0), st, 1);

@@ -16,8 +16,10 @@
 
 #ifdef PCAMV_HOST_EMU
 #define PCAMV_LANE0 1
+#define PCAMV_RFL(x) (x)
 #else
 #define PCAMV_LANE0 (LANE() == 0)
+#define PCAMV_RFL(x) rfl(x)
 #endif
 
 /* what follows the decision: (--subme >= 6) the pass-1 reconstruction and the entropy coder's bookkeeping, then the record and the
@@ -213,15 +215,26 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
      * dozen dependent round trips at the head of a task that is only ~3 k instructions long */
     pcamv_mb_t *r = (pcamv_mb_t *)L->ccost;
     PCAMV_WAVE_SYNC();
+#ifndef PCAMV_HOST_EMU
+    /* asked for in the same round trip as the record, before anything is known about the macroblock: "is any carrier of it flipped" and
+     * its first-pass reconstruction (used when the macroblock turns out to be what the first pass made, below: 7 of 8) */
+    uint32_t pre_y = 0, pre_c = 0;
+    int any_flip = 1;
+    {
+        const int lane = LANE();
+        if (F.rec_is_pass1) {
+            pre_y = *(const uint32_t *)(F.rec[0] + (size_t)(mb_y * 16 + (lane >> 2)) * F.w + mb_x * 16 + (lane & 3) * 4);
+            if (lane < 32) pre_c = *(const uint32_t *)(((lane >> 4) ? F.rec[2] : F.rec[1]) + (size_t)(mb_y * 8 + ((lane & 15) >> 1)) * (F.w >> 1) + mb_x * 8 + (lane & 1) * 4);
+        }
+        if (F.mbflip) any_flip = F.mbflip[xy];
+    }
+#else
+    const int any_flip = 1;
+#endif
     FOR_CAND(i, (int)(sizeof(pcamv_mb_t) / 4) + 1) {
         if (i < (int)(sizeof(pcamv_mb_t) / 4)) ((uint32_t *)r)[i] = ((const uint32_t *)&F.rec_mb[xy])[i];
         else L->ccost[191] = F.car_base ? F.car_base[xy] : 0;
     }
-#ifndef PCAMV_HOST_EMU
-    /* several macroblocks of a row per task: the previous one's write-through stores (filtered pixels, final motion, non-zero flags)
-     * must have landed before this one's agent-scope loads of them -- waited for here, with the record's load in flight beside them */
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     PCAMV_WAVE_SYNC();
     mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
     L->i_type = r->i_type; L->i_partition = r->i_partition;
@@ -237,7 +250,9 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
         const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, r->used, slots);
         const int base = L->ccost[191];
         PCAMV_WAVE_SYNC();
-        FOR_CAND(j, n) L->cxy[j] = F.flip ? (uint32_t)(F.flip[base + j] == 1) : 0u;     /* its carriers' flip flags: one more round trip */
+        /* its carriers' flip flags: one more round trip, for the macroblocks that have a flipped carrier at all */
+        if (PCAMV_RFL(any_flip)) { FOR_CAND(j, n) L->cxy[j] = F.flip ? (uint32_t)(F.flip[base + j] == 1) : 0u; }
+        else { FOR_CAND(j, n) L->cxy[j] = 0u; }
         PCAMV_WAVE_SYNC();
         FOR_CAND(i, 16) {
             const int s = carrier_of_block(L->i_type, L->i_partition, L->sub_part, i);
@@ -258,7 +273,13 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
         L->nnz_mask = F.nnz[xy];
 #else
         L->nnz_mask = rfl((int)F.nnz[xy]);
-        prim_load_rec(F, L);
+        {   /* (the layout of prim_store_rec) */
+            const int lane = LANE();
+            PCAMV_WAVE_SYNC();
+            sts4(L->pred + (lane >> 2) * 16 + (lane & 3) * 4, pre_y);
+            if (lane < 32) sts4(L->pred + 256 + ((lane & 15) >> 1) * 16 + (lane >> 4) * 8 + (lane & 1) * 4, pre_c);
+            PCAMV_WAVE_SYNC();
+        }
 #endif
     } else {
         mb_encode(F, L);
