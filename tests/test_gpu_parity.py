@@ -594,6 +594,16 @@ def test_pass2_and_loop_filter_match_oracle(pc, cfg):
     assert np.array_equal(fin2["mv"], fo2["mv"])
     for a, b in zip(dbk2, dbk_o2):
         assert np.array_equal(a, b)
+    # ... and a second pass over the SAME analysis once more, with another map: by now the frame's reconstruction planes hold the
+    # filtered picture, and nothing of it may be taken for the first pass' pixels (the library reuses those only while they are there)
+    flips3 = (np.random.default_rng(seed + 100).random(n) < rate).astype(np.uint8)
+    fin3, rec3, dbk3 = enc.pass2_pframe(flips3)
+    fo3, _, rec_o3, dbk_o3, _ = o2.pass2_pframe(qp, mbs_o2, flips3)
+    assert np.array_equal(fin3["mv"], fo3["mv"])
+    for a, b, nm in zip(rec3, rec_o3, "yuv"):
+        assert np.array_equal(a, b), f"second call, pass-2 reconstruction {nm}"
+    for a, b, nm in zip(dbk3, dbk_o3, "yuv"):
+        assert np.array_equal(a, b), f"second call, deblocked {nm}"
     enc.close(); o.close(); o2.close()
 
 
