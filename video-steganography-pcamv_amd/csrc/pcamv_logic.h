@@ -799,19 +799,31 @@ PCAMV_DEV int rd_cost_mb(const FrameDev &F, MBLocal *L)
 {
     L->b_skip_mc = 0;
     const unsigned long long t_e = PROF_T();
+#if defined(PCAMV_EXP_DBL) && PCAMV_EXP_DBL == 1      /* instruction-count experiments only: one part of a trial made twice */
+    mb_encode(F, L, 0, 1);
+#endif
     mb_encode(F, L, 0, 1);
     PROF_ADD(18, t_e);
     const unsigned long long t_s = PROF_T();
+#if defined(PCAMV_EXP_DBL) && PCAMV_EXP_DBL == 2
+    { volatile int sink = prim_ssd_mb(F, L); (void)sink; }
+#endif
     const int ssd = prim_ssd_mb(F, L);
     PROF_ADD(19, t_s);
     int bits;
     if (F.b_cabac) {
         const unsigned long long t_h = PROF_T();
         CabWalk C;
+#if defined(PCAMV_EXP_DBL) && PCAMV_EXP_DBL == 3
+        { CabWalk C2; prim_cab_begin(L, C2, 1); cabac_mb_header(F, L, C2); volatile int sink = prim_cab_end(L, C2, 0); (void)sink; }
+#endif
         prim_cab_begin(L, C, 1);                             /* a size trial: the slice's states are read, never written */
         cabac_mb_header(F, L, C);
         PROF_ADD(20, t_h);
         const unsigned long long t_r = PROF_T();
+#if defined(PCAMV_EXP_DBL) && PCAMV_EXP_DBL == 4
+        { CabWalk C2 = C; prim_cab_residual(F, L, C2, 0); volatile int sink = C2.vbits; (void)sink; }
+#endif
         prim_cab_residual(F, L, C, 0);
         const int f8 = prim_cab_end(L, C, 0);
         PROF_ADD(21, t_r);
@@ -859,6 +871,9 @@ PCAMV_DEV unsigned long long rd_cost_part8(const FrameDev &F, MBLocal *L, int i8
  * counts = 0: a trial the decision will not look at (P_8x8 while nothing is embedded, analyse.c:2841). */
 PCAMV_DEV int rd_trial(const FrameDev &F, MBLocal *L, int counts)
 {
+#ifdef PCAMV_EXP_DOUBLE_TRIAL      /* instruction-count experiment only: every RD trial made twice (same result) */
+    { volatile int sink = rd_cost_mb(F, L); (void)sink; }
+#endif
     const int cost = rd_cost_mb(F, L);
     if (counts && cost < L->snap_cost) { L->snap_cost = cost; L->snap_part = L->i_partition; prim_rd_keep(F, L); }
     return cost;

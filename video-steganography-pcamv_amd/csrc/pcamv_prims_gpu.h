@@ -905,7 +905,7 @@ __device__ __forceinline__ int quad_had2x2(int v, int q)
  *     plain sums decide identically. */
 /* lv: also leave the quantised levels in scan order (L->coef per block, L->cdc chroma DC in zigzag_scan_2x2_dc order) and the
  * per-block non-zero flags as the entropy coder sees them (L->nzc: zero where an 8x8 / the macroblock / a chroma plane was dropped) */
-__device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L, int lv_ = 0)
+__device__ __forceinline__ void prim_mb_transform_v1(const FrameDev &F, MBLocal *L, int lv_ = 0)
 {
     PCAMV_WAVE_SYNC();
     const int lv = rfl(lv_);
@@ -961,6 +961,183 @@ __device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L,
             const int q = lane & 3;
             L->cdc[ch][q == 1 ? 2 : q == 2 ? 1 : q] = (int16_t)dcq;     /* zigzag_scan_2x2_dc: d[0][0], d[1][0], d[0][1], d[1][1] */
             if (q == 0) L->nzc[scan8_all_of(25 + ch)] = (uint8_t)(nzdc != 0);
+        }
+        if (lane == 0) L->nzc[scan8_all_of(24)] = 0;
+    }
+    PCAMV_WAVE_SYNC();
+}
+/* lane ^ 4 inside a row of 16: two row shifts, each written to the banks (quads) it is right for */
+__device__ __forceinline__ int dpp_x4(int v)
+{
+    const int a = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);
+    return __builtin_amdgcn_update_dpp(a, v, 0x114, 0xf, 0xa, false);
+}
+/* The same stage with TWO lanes per 4x4 block (round 3): a lone macroblock has 24 blocks, one per lane left 40 lanes idle through ~900
+ * instructions.  Lane 2 b + h (luma, b in x264 block order: an 8x8 is eight lanes) and 32 + 2 cb + h (chroma, a plane is eight lanes)
+ * holds rows 0 and 3 (h = 0) or 1 and 2 (h = 1) of its block: the horizontal transform and the first vertical butterfly (row A +- row B)
+ * are in-lane, the second one exchanges with the partner lane (h = 0 ends with the coefficients of vertical frequency 0 and 1, h = 1 with
+ * 2 and 3, all four horizontal frequencies each); quantisation, scan masks and dequantisation work on eight coefficients instead of
+ * sixteen; the inverse transform runs the other way round (horizontal pass in-lane per vertical frequency, one exchange, and h = 0 ends
+ * with rows 0 and 3, h = 1 with rows 1 and 2 -- the rows it loaded).  Same results as prim_mb_transform_v1, the arithmetic is the
+ * reference's (dct.c:122-170, quant.c, macroblock.c) value for value. */
+__device__ __forceinline__ void prim_mb_transform(const FrameDev &F, MBLocal *L, int lv_ = 0)
+{
+    PCAMV_WAVE_SYNC();
+    const int lv = rfl(lv_);
+    const int lane = LANE();
+    const bool is_l = lane < 32, is_c = lane >= 32 && lane < 48;
+    const int h = lane & 1, blk = is_l ? lane >> 1 : 16 + ((lane - 32) >> 1);          /* 0..15 luma, 16..19 U, 20..23 V (the index of L->coef / nzc) */
+    const int cb = (lane - 32) >> 1, ch = cb >> 2, ci = cb & 3;
+    const int px = is_l ? 4 * blk_x_of(blk) : ch * 8 + (ci & 1) * 4;
+    const int py = is_l ? 4 * blk_y_of(blk) : 16 + (ci >> 1) * 4;
+    const int ra = h ? 1 : 0, rb = h ? 2 : 3;                                      /* this lane's two rows */
+    const int sgn = h ? -1 : 1;
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};           /* coefficients: c[j] = (horizontal frequency j, vertical frequency 2 h), c[4 + j] = (j, 2 h + 1) */
+    int nz = 0, score = 0, rawdc = 0, big = 0;
+    unsigned zm = 0;
+    if (is_l || is_c) {
+        int t[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int y = k ? rb : ra;
+            const uint32_t e = lds4(L->fenc + (py + y) * 16 + px), p = lds4(L->pred + (py + y) * 16 + px);
+            const int d0 = (int)(e & 255) - (int)(p & 255), d1 = (int)((e >> 8) & 255) - (int)((p >> 8) & 255);
+            const int d2 = (int)((e >> 16) & 255) - (int)((p >> 16) & 255), d3 = (int)(e >> 24) - (int)(p >> 24);
+            const int s03 = d0 + d3, s12 = d1 + d2, d03 = d0 - d3, d12 = d1 - d2;
+            t[k][0] = s03 + s12; t[k][1] = 2 * d03 + d12; t[k][2] = s03 - s12; t[k][3] = d03 - 2 * d12;
+        }
+        /* vertical: rows (0, 3) / (1, 2) in-lane, then with the partner: h = 0: s03 + s12, 2 d03 + d12; h = 1: s03 - s12, d03 - 2 d12 */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s = t[0][j] + t[1][j], d = t[0][j] - t[1][j];
+            c[j] = mad24s(s, sgn, dpp_qp1(s));
+            c[4 + j] = mad24s(d, 2 * sgn, dpp_qp1(d));
+        }
+    }
+    rawdc = h ? 0 : c[0];
+    if (!is_l && !h) c[0] = 0;
+    {
+        /* quantiser and dequantiser of the lane's eight positions: class (j & 1) + (vertical frequency & 1) -- c[0..3]: 0 1 0 1, c[4..7]: 1 2 1 2 */
+        const int mf0 = is_l ? F.q_mf[0][0] : F.q_mf[1][0], mf1 = is_l ? F.q_mf[0][1] : F.q_mf[1][1], mf2 = is_l ? F.q_mf[0][2] : F.q_mf[1][2];
+        const int bs0 = is_l ? F.q_bias[0][0] : F.q_bias[1][0], bs1 = is_l ? F.q_bias[0][1] : F.q_bias[1][1], bs2 = is_l ? F.q_bias[0][2] : F.q_bias[1][2];
+        const int dq0 = is_l ? F.dq_mf[0] : F.dq_mf_c[0], dq1 = is_l ? F.dq_mf[1] : F.dq_mf_c[1], dq2 = is_l ? F.dq_mf[2] : F.dq_mf_c[2];
+        const int bm0 = (int)mul24u((uint32_t)bs0, (uint32_t)mf0), bm1 = (int)mul24u((uint32_t)bs1, (uint32_t)mf1), bm2 = (int)mul24u((uint32_t)bs2, (uint32_t)mf2);
+        /* scan positions (inverse zigzag of raster index 4 j + vertical frequency): vf 0: 0 1 5 6, 1: 2 4 7 12, 2: 3 8 11 13, 3: 9 10 14 15 */
+        int mx = 0, mn = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = k & 3, odd = k >> 2, cls = (j & 1) + odd;
+            const int mf = cls == 0 ? mf0 : cls == 1 ? mf1 : mf2, bm = cls == 0 ? bm0 : cls == 1 ? bm1 : bm2;
+            constexpr int pos0[8] = {0, 1, 5, 6, 2, 4, 7, 12}, pos1[8] = {3, 8, 11, 13, 9, 10, 14, 15};
+            const int q = mad24s(c[k], mf, c[k] < 0 ? 65535 - bm : bm) >> 16;
+            c[k] = q;
+            zm |= q != 0 ? (h ? 1u << pos1[k] : 1u << pos0[k]) : 0u;
+            mx = imax(mx, q); mn = imin(mn, q);
+        }
+        big = mx > 1 || mn < -1;
+        zm |= (unsigned)dpp_qp1((int)zm);
+        big |= dpp_qp1(big);
+        nz = zm != 0;
+        if (lv && nz && (is_l || is_c)) {          /* the quantised levels in scan order (h->dct.luma4x4), for the entropy coder's size walk */
+            int16_t *lv_out = L->coef[blk];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                constexpr int pos0[8] = {0, 1, 5, 6, 2, 4, 7, 12}, pos1[8] = {3, 8, 11, 13, 9, 10, 14, 15};
+                lv_out[h ? pos1[k] : pos0[k]] = (int16_t)c[k];
+            }
+        }
+        if (nz) {
+            const unsigned zr = is_l ? zm << 1 : zm, z = zr | 1u;
+            const unsigned s1 = z << 1, s3 = s1 | s1 << 1 | z << 3, s6 = s3 | s3 << 3;
+            score = big ? 9 : __builtin_popcount(zr & s1) + __builtin_popcount(zr & s3) + __builtin_popcount(zr & s6);
+            const int qbits = (is_l ? F.qp : F.chroma_qp) / 6 - 4;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int cls = (k & 1) + (k >> 2), dqv = cls == 0 ? dq0 : cls == 1 ? dq1 : dq2;
+                c[k] = qbits >= 0 ? (int16_t)(mul24s(c[k], dqv) << qbits) : (int16_t)((mul24s(c[k], dqv) + (1 << (-qbits - 1))) >> (-qbits));
+            }
+        }
+    }
+    /* luma: 8x8 sums over the eight lanes of an 8x8, macroblock sum over lanes 0..31; chroma: the plane's eight lanes */
+    const int sc = (nz && F.b_dct_decimate && !h) ? score : 0;
+    int q8 = sc + dpp_qp1(sc); q8 += dpp_qp2(q8); q8 += dpp_hmir(q8);
+    int any8 = nz | dpp_qp2(nz); any8 |= dpp_hmir(any8);
+    const int r16 = q8 + dpp_mir(q8);
+    const int row = __builtin_amdgcn_readlane(r16, 0) + __builtin_amdgcn_readlane(r16, 16);
+    const bool keep = F.b_dct_decimate ? (q8 >= 4 && row >= 6) : any8 != 0;
+    /* chroma DC: 2x2 transform over the plane's four blocks (their h = 0 lanes, two apart): butterflies with lane ^ 2, then lane ^ 4; the
+     * network leaves coefficient (k & 1) * 2 + (k >> 1) in the lane of block k -- zigzag_scan_2x2_dc's place k -- and, run again on the
+     * quantised values, block k's reconstructed DC in the lane of block k */
+    const int s2 = lane & 2 ? -1 : 1, s4 = lane & 4 ? -1 : 1;
+    int cdc = mad24s(rawdc, s2, dpp_qp2(rawdc));
+    cdc = mad24s(cdc, s4, dpp_x4(cdc));
+    int dcq;
+    { const int mf = F.q_mf[1][0] >> 1, bias = F.q_bias[1][0] << 1;
+      dcq = cdc > 0 ? ((bias + cdc) * mf >> 16) : -((bias - cdc) * mf >> 16); }
+    if (h || !is_c) dcq = 0;
+    int nzdc = dcq != 0; nzdc |= dpp_qp1(nzdc); nzdc |= dpp_qp2(nzdc); nzdc |= dpp_hmir(nzdc);
+    int dmf = F.dq_mf_c[0], qbits = F.chroma_qp / 6 - 5;
+    if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+    int idc = mad24s(dcq, s2, dpp_qp2(dcq));
+    idc = mad24s(idc, s4, dpp_x4(idc));
+    int rdc = (int16_t)(idc * dmf >> -qbits);
+    {   /* both lanes of the block (the exchange made by all lanes, THEN the choice: inside `h ? dpp : x` only the odd lanes would
+         * execute it, and a DPP read of a lane that is switched off returns 0) */
+        const int other = dpp_qp1(rdc);
+        rdc = h ? other : rdc;
+    }
+    const int cmode = (q8 < 7 && F.b_dct_decimate) || !any8 ? (nzdc ? 1 : 0) : 2;
+    const unsigned long long keep_mask = __ballot(is_l && keep), ac_mask = __ballot(is_c && cmode == 2);
+    const bool inv = is_l ? keep && nz : is_c && cmode == 2;
+    if (is_c && cmode == 2 && nzdc && !h) c[0] = (int16_t)rdc;
+    if (inv) {
+        /* inverse: per vertical frequency the horizontal pass (in-lane), then the vertical one with the partner */
+        int u[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c0 = c[4 * k], c1 = c[4 * k + 1], c2 = c[4 * k + 2], c3 = c[4 * k + 3];
+            const int s02 = c0 + c2, d02 = c0 - c2, s13 = c1 + (c3 >> 1), d13 = (c1 >> 1) - c3;
+            u[k][0] = (int16_t)(s02 + s13); u[k][1] = (int16_t)(d02 + d13); u[k][2] = (int16_t)(d02 - d13); u[k][3] = (int16_t)(s02 - s13);
+        }
+        uint32_t oa = 0, ob = 0;
+        const uint8_t *pa = L->pred + (py + ra) * 16 + px, *pb = L->pred + (py + rb) * 16 + px;
+        const uint32_t va = lds4(pa), vb = lds4(pb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            /* h = 0 holds t[0][i], t[1][i] and makes s02, s13; h = 1 holds t[2][i], t[3][i] and makes d02, d13 */
+            const int x = mad24s(u[0][i], sgn, dpp_qp1(u[0][i])) + 32;
+            const int y = mad24s(u[1][i], sgn, dpp_qp1(u[1][i]) >> 1);
+            const int r_a = (int16_t)((x + y) >> 6), r_b = (int16_t)((x - y) >> 6);      /* rows 0 / 3 (h = 0), 1 / 2 (h = 1) */
+            oa |= (uint32_t)clip3i((int)((va >> (8 * i)) & 255) + r_a, 0, 255) << (8 * i);
+            ob |= (uint32_t)clip3i((int)((vb >> (8 * i)) & 255) + r_b, 0, 255) << (8 * i);
+        }
+        sts4((uint8_t *)pa, oa); sts4((uint8_t *)pb, ob);
+    } else if (is_c && cmode == 1) {
+        const int v = (rdc + 32) >> 6;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            uint8_t *dst = L->pred + (py + (k ? rb : ra)) * 16 + px;
+            uint32_t p = lds4(dst), o = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) o |= (uint32_t)clip3i((int)((p >> (8 * x)) & 255) + v, 0, 255) << (8 * x);
+            sts4(dst, o);
+        }
+    }
+    {
+        /* one bit per block out of the even lanes' bits */
+        unsigned m = (unsigned)__ballot(is_l && keep && nz && !h);
+        m = (m | m >> 1) & 0x33333333u; m = (m | m >> 2) & 0x0f0f0f0fu; m = (m | m >> 4) & 0x00ff00ffu; m = (m | m >> 8) & 0xffffu;
+        L->nnz_mask = (int)m;
+    }
+    L->cbp_luma = (int)((keep_mask & 1) | ((keep_mask >> 7) & 2) | ((keep_mask >> 14) & 4) | ((keep_mask >> 21) & 8));
+    const unsigned long long dc_mask = __ballot(is_c && nzdc);
+    L->cbp_chroma = ac_mask ? 2 : dc_mask ? 1 : 0;                 /* encoder/macroblock.c:364-372: DC-only chroma */
+    if (lv && !h) {
+        if (is_l) L->nzc[scan8_of(blk)] = (uint8_t)(keep && nz);
+        else if (is_c) {
+            L->nzc[scan8_all_of(blk)] = (uint8_t)(cmode == 2 && nz);
+            L->cdc[ch][ci] = (int16_t)dcq;                              /* (the network's place = zigzag_scan_2x2_dc's) */
+            if (ci == 0) L->nzc[scan8_all_of(25 + ch)] = (uint8_t)(nzdc != 0);
         }
         if (lane == 0) L->nzc[scan8_all_of(24)] = 0;
     }
