@@ -612,6 +612,11 @@ static inline void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx, int b)
     C.S[ctx] = (uint8_t)(w & 255u); C.bits += (int)(w >> 8);
 }
 static inline void prim_cb_bypass(CabWalk &C, int f8) { C.bits += f8; }
+static inline void prim_cb_run(MBLocal *L, CabWalk &C, int ctx, int ones, int zero)
+{
+    for (int i = 0; i < ones; i++) prim_cb_dec(L, C, ctx, 1);
+    if (zero) prim_cb_dec(L, C, ctx, 0);
+}
 static inline int prim_cab_end(MBLocal *L, CabWalk &C, int commit) { if (commit) memcpy(L_CAB(L, 0), C.S, 464); else memcpy(L_CABT(L), C.S, PCAMV_CAB_USED); return C.bits; }
 static inline void prim_rd_keep(const FrameDev &F, MBLocal *L)
 {

@@ -745,9 +745,10 @@ PCAMV_DEV void cb_mvd_cpn(MBLocal *L, CabWalk &C, int idx, int l, int mvd)      
     const int a = iabs(mvd), base = l ? 47 : 40;
     prim_cb_dec(L, C, base + (amvd > 2) + (amvd > 32), a != 0);
     if (!a) return;
-    for (int i = 1; i < imin(a, 9); i++) prim_cb_dec(L, C, base + imin(i + 2, 6), 1);      /* contexts 3, 4, 5, 6, 6, .. */
-    if (a < 9) prim_cb_dec(L, C, base + imin(a + 2, 6), 0);
-    else prim_cb_bypass(C, (size_ue_of((unsigned)(a - 9 + 7)) - 3) << 8);                   /* Exp-Golomb k = 3 suffix */
+    for (int i = 1; i < imin(a, 4); i++) prim_cb_dec(L, C, base + i + 2, 1);               /* contexts 3, 4, 5, then 6, 6, .. */
+    if (a >= 4) prim_cb_run(L, C, base + 6, imin(a, 9) - 4, a < 9);                        /* (the decisions on context 6 as one run) */
+    else prim_cb_dec(L, C, base + a + 2, 0);
+    if (a >= 9) prim_cb_bypass(C, (size_ue_of((unsigned)(a - 9 + 7)) - 3) << 8);            /* Exp-Golomb k = 3 suffix */
     prim_cb_bypass(C, 256);                                                                /* sign */
 }
 PCAMV_DEV void cb_mvd(MBLocal *L, CabWalk &C, int idx, int width, int height)     /* encoder/cabac.c:452-470 */

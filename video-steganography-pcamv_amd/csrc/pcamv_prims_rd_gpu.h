@@ -531,14 +531,17 @@ __device__ __forceinline__ int prim_ssd_mb(const FrameDev &F, MBLocal *L)
  * (15 k cycles per header, 28 k per residual of a lone wave's macroblock).  Header contexts 0..87 (mb_skip, mb_type, sub_mb_type,
  * mvd, mb_qp_delta, coded_block_pattern): context c in lane c & 63 of register c >> 6.  The slice's states (LDS) are read at
  * the beginning; the states the walk ends in go to the slice's (committing walk) or to the trial copy. */
-struct CabWalk { int s0, s1, n0, n1, bits, vbits; unsigned long long q0, q1; };
+/* (round 3: ONE state / queue register pair per lane.  A P slice's macroblock header touches contexts 11..23, 40..53, 60 and 73..84
+ * only; lanes 24..35 -- whose own contexts, B-slice macroblock types, it never touches -- hold 73..84, so a header is one queue
+ * walk, not two, and a decision needs no choice of register.) */
+struct CabWalk { int s, n, tot, bits, vbits; unsigned long long q; };
 __device__ __forceinline__ void cabq_push(unsigned long long &q, int &n, int owner, int bin)
 {
     const bool me = LANE() == owner;
     q |= me ? (unsigned long long)(unsigned)bin << n : 0ull;
     n += me ? 1 : 0;
 }
-/* `ones` 1-bins followed, if `zero`, by one 0-bin: the unary prefix of a level */
+/* `ones` 1-bins followed, if `zero`, by one 0-bin: the unary prefix of a level / of an MV difference */
 __device__ __forceinline__ void cabq_push_run(unsigned long long &q, int &n, int owner, int ones, int zero)
 {
     const bool me = LANE() == owner;
@@ -559,6 +562,8 @@ __device__ __forceinline__ int cabq_resolve(const uint32_t *T, int &st, unsigned
     q = 0;
     return bits;
 }
+__device__ __forceinline__ int cab_hdr_ctx(int lane) { return lane >= 24 && lane < 36 ? lane + 49 : lane; }       /* the context a lane owns during a header */
+__device__ __forceinline__ int cab_hdr_lane(int ctx) { return ctx < 64 ? ctx : ctx - 49; }
 /* trial: a size trial -- its end states go to the trial copy (which starts as a copy of the slice's), never to the slice's */
 __device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C, int trial_)
 {
@@ -569,27 +574,40 @@ __device__ __forceinline__ void prim_cab_begin(MBLocal *L, CabWalk &C, int trial
         const uint32_t *s = (const uint32_t *)S; uint32_t *d = (uint32_t *)L_CABT(L);
         d[lane] = s[lane]; if (lane < PCAMV_CAB_USED / 4 - 64) d[64 + lane] = s[64 + lane];
     }
-    C.s0 = S[lane]; C.s1 = lane < 24 ? S[64 + lane] : 0; C.bits = 0; C.vbits = 0;
-    C.q0 = C.q1 = 0; C.n0 = C.n1 = 0;
+    C.s = S[cab_hdr_ctx(lane)]; C.bits = 0; C.vbits = 0;
+    C.q = 0; C.n = 0; C.tot = 0;
+}
+__device__ __forceinline__ void prim_cab_flush(MBLocal *L, CabWalk &C)
+{
+    C.vbits += cabq_resolve(L_CTAB(L), C.s, C.q, C.n);
+    C.tot = 0;
 }
 __device__ __forceinline__ void prim_cb_dec(MBLocal *L, CabWalk &C, int ctx_, int b_)
 {
     const int ctx = rfl(ctx_), b = rfl(b_);
-    (void)L;
-    if (ctx < 64) cabq_push(C.q0, C.n0, ctx, b);           /* (a header makes fewer than 64 decisions in all: no queue can overflow) */
-    else cabq_push(C.q1, C.n1, ctx - 64, b);
+    /* (no queue may pass 64 bins: the decisions since the last walk are counted on the scalar side; 16 MV differences of a macroblock
+     * in 4x4 partitions can put more than that on one context) */
+    if (rfl(C.tot) >= 48) prim_cab_flush(L, C);
+    cabq_push(C.q, C.n, cab_hdr_lane(ctx), b);
+    C.tot++;
+}
+/* `ones` 1-bins and, if zero_, a 0-bin on one context (ones + zero_ <= 16) */
+__device__ __forceinline__ void prim_cb_run(MBLocal *L, CabWalk &C, int ctx_, int ones_, int zero_)
+{
+    const int ctx = rfl(ctx_), ones = rfl(ones_), zero = rfl(zero_);
+    if (rfl(C.tot) >= 48) prim_cab_flush(L, C);
+    cabq_push_run(C.q, C.n, cab_hdr_lane(ctx), ones, zero);
+    C.tot += ones + zero;
 }
 __device__ __forceinline__ void prim_cb_bypass(CabWalk &C, int f8) { C.bits += rfl(f8); }
 __device__ __forceinline__ int prim_cab_end(MBLocal *L, CabWalk &C, int commit_)
 {
     const int lane = LANE();
     const uint32_t *T = L_CTAB(L);
-    C.vbits += cabq_resolve(T, C.s0, C.q0, C.n0);
-    C.vbits += cabq_resolve(T, C.s1, C.q1, C.n1);
+    C.vbits += cabq_resolve(T, C.s, C.q, C.n);
     {
         uint8_t *S = rfl(commit_) ? L_CAB(L, 0) : L_CABT(L);
-        S[lane] = (uint8_t)C.s0;
-        if (lane < 24) S[64 + lane] = (uint8_t)C.s1;
+        S[cab_hdr_ctx(lane)] = (uint8_t)C.s;
     }
     const int total = rfl(C.bits) + wave_sum_all(C.vbits);
     PCAMV_WAVE_SYNC();
