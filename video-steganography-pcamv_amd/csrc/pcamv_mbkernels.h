@@ -197,6 +197,9 @@ PCAMV_DEV void mbk_rca_all(const FrameDev &F, MBLocal *L, Analysis *a, int xy, i
 }
 PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy, int fused = 0, int have_rec = 0)
 {
+#ifdef PCAMV_EXP_DBL_RCA      /* instruction-count experiment only */
+    { const int n_ = mbk_recon(F, L, a, xy, fused, have_rec); mbk_rca_all(F, L, a, xy, n_); mbk_rca_all(F, L, a, xy, n_); return; }
+#endif
     mbk_rca_all(F, L, a, xy, mbk_recon(F, L, a, xy, fused, have_rec));
 }
 
