@@ -126,19 +126,10 @@ enum { I4_V, I4_H, I4_DC, I4_DDL, I4_DDR, I4_VR, I4_HD, I4_VL, I4_HU, I4_DC_LEFT
 /* Per-macroblock working set.  On the GPU this lives in LDS (one wavefront = one macroblock);
  * every lane executes the control code redundantly on wave-uniform values. */
 struct MBLocal {
+    /* (round 3: what the second pass of a macroblock touches comes first -- up to and including `pred` --, so that its kernel only
+     * allocates that much LDS, PCAMV_PASS2_LDS, and fits six waves per SIMD instead of four; recb .. the union stay contiguous in this
+     * order: the Hadamard exhaustive search's survivor list runs across them, TESA_SLOT) */
     uint8_t fenc[24 * 16];         /* Y 16x16 then U|V 8x8 side by side, stride 16 (x264 fenc_buf layout) */
-    uint8_t recb[24 * 16];         /* reconstruction in the same layout (fenc_buf_ih) */
-    uint8_t recb0[24 * 16];        /* reconstruction of the macroblock as decided: shared by all its carriers' first RCA step */
-    uint8_t pred[24 * 16];         /* prediction -> reconstruction, same layout */
-    union {
-        struct {                       /* P_SKIP probe (search phase): per 4x4 block levels and their summaries */
-            int16_t coef[24][16];      /* luma 0..15, U 16..19, V 20..23 */
-            int16_t cdc[2][4];
-            int blk_nz[24], blk_score[24];
-            int red[64];               /* scratch for cross-lane work */
-        };
-        uint8_t pred4[4][24 * 16];     /* RCA phase: prediction -> reconstruction of four re-encodes made together */
-    };
     int16_t cmv[48][2];
     int8_t cref[48];
     int16_t pskip_mv[2];
@@ -152,9 +143,21 @@ struct MBLocal {
     int nnz_mask;                  /* luma blocks with non-zero levels after the transform stage (bit = x264 block index) */
     uint32_t cxy[64];              /* candidate list of the running evaluation: x | y << 16, quarter-pel; CAND_NONE = skip */
     int ccost[192];                /* cost of every listed candidate ([64..191]: per-plane chroma terms of the probe kernel) */
+    int slots[16];
+    uint8_t recb[24 * 16];         /* reconstruction in the same layout (fenc_buf_ih) */
+    uint8_t recb0[24 * 16];        /* reconstruction of the macroblock as decided: shared by all its carriers' first RCA step */
+    uint8_t pred[24 * 16];         /* prediction -> reconstruction, same layout */
+    union {
+        struct {                       /* P_SKIP probe (search phase): per 4x4 block levels and their summaries */
+            int16_t coef[24][16];      /* luma 0..15, U 16..19, V 20..23 */
+            int16_t cdc[2][4];
+            int blk_nz[24], blk_score[24];
+            int red[64];               /* scratch for cross-lane work */
+        };
+        uint8_t pred4[4][24 * 16];     /* RCA phase: prediction -> reconstruction of four re-encodes made together */
+    };
     int mvc16[9][2];               /* candidate MVs of the 16x16 search */
     int nbc[12];                   /* neighbourhood costs of the RCA step */
-    int slots[16];
     /* reference window of the RCA step of a 16x16 macroblock: every MV it touches lies within +-3 quarter
      * pels of the decided one, so 4 luma planes of 24 x 20 and 2 chroma planes of 16 x 12 bytes hold all
      * the reference pixels of its re-encodes and nine-point lists */
@@ -182,6 +185,7 @@ struct MBLocal {
     int mvc_tmp[9][2];
 #endif
 };
+#define PCAMV_PASS2_LDS ((int)offsetof(MBLocal, coef))       /* everything up to and including pred */
 /* Storage that is idle while the RD decision runs is reused (no LDS growth): the RCA reference window holds the CABAC
  * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA
  * reconstruction buffers hold the intra 4x4 analysis' picture (17 rows of 32: row -1 and column -1 are the neighbours);

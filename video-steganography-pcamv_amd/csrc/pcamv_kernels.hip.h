@@ -747,12 +747,18 @@ int pcamv_flow_rd_waves_per_cu_spec4(void);
  * costs no cache maintenance -- final motion and reconstructed pixels are stored write-through (NB_ST*) and the
  * filter reads its neighbourhood with agent-scope loads (NB_LD*).  (With an agent-scope release + acquire per
  * macroblock this was slower than one launch per anti-diagonal: 245 vs 176 ms per closed-loop step at G=256.) */
+#ifndef PCAMV_PASS2_OCC
+#define PCAMV_PASS2_OCC 6         /* waves per SIMD the second-pass kernel's registers are held to (its LDS allows eight) */
+#endif
 #ifdef PCAMV_MAIN_TU
-static __global__ void __launch_bounds__(64, PCAMV_FLOW_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
+static __global__ void __launch_bounds__(64, PCAMV_PASS2_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
 {
-    __shared__ MBLocal L;
+    /* only the head of the per-macroblock storage (PCAMV_PASS2_LDS: the fields the second pass touches come first in MBLocal): 4.3 instead
+     * of 8.9 KB per wave with the filter's staging area, so the CU holds the six waves per SIMD the kernel's 83 VGPRs allow -- it
+     * waits for memory three quarters of its time, more waves in flight is what it can use */
+    __shared__ __attribute__((aligned(16))) uint8_t Lraw[PCAMV_PASS2_LDS];
     __shared__ DeblockLDS D;
-    flow_loop<1, 0>(Fs, fl, L, nullptr, &D);
+    flow_loop<1, 0>(Fs, fl, *reinterpret_cast<MBLocal *>(Lraw), nullptr, &D);
 }
 #endif
 
