@@ -400,6 +400,214 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     if (lane >= 16 && lane < 32 && my > 0) { const int pl = (lane - 16) >> 3, j = (lane - 16) & 7, r = j >> 1, c = (j & 1) * 4; uint8_t *dst = pl ? F.rec[2] : F.rec[1];
       NB_ST32(dst + (size_t)(cgy - 4 + r) * CW + cgx + c, *(const uint32_t *)&sc[pl][r][c + 4]); }
 }
+/* ------------------------------------------------------------------ the second pass of a RUN of macroblocks of a row (k_pass2_deblock_flow)
+ * A task of the second-pass kernel is up to eight macroblocks of a row.  Taken one by one, each cost two or three memory round trips (record,
+ * pixels, the filter's borders), fetched 4 KB for its 0.6 KB (a macroblock's sixteen 16-byte rows are sixteen cache lines, which its seven
+ * neighbours in the run fetch again) and stored its rows as partial lines.  Here the run is ONE tile in LDS: its pixels with the four
+ * rows above and the four columns to the left (rows of up to 132 bytes: whole lines), the eight records and the neighbours' side of the
+ * outer edges come in one round trip; the macroblocks are then reconstructed (where the embedding changed them) and filtered in place, the
+ * left neighbour's side of an edge handed from one to the next in LDS; the tile goes back in rows. */
+#define P2_TW 144        /* tile row pitch, luma: columns -4 .. 127 at [c + 4] */
+#define P2_CW 80         /* chroma: columns -4 .. 63 at [c + 4] */
+struct P2Unit {
+    uint8_t ty[20][P2_TW];              /* rows -4 .. 15 at [r + 4] */
+    uint8_t tc[2][12][P2_CW];
+    pcamv_mb_t rec[8];
+    int car_base[8], mbflip[8], nnz1[8];
+    unsigned t_nnz[8]; uint32_t t_mv[8][4]; int t_ref[8][4];      /* the upper neighbours' bottom row of 4x4 blocks */
+    unsigned l_nnz; uint32_t l_mv[4]; int l_ref[4];                 /* the left neighbour's right column: of the run's first macroblock from memory, then handed on */
+    uint8_t sbs[2][4][4];
+};
+#define P2_LSLOTS (20 * 33)             /* luma dwords of the tile: row r = i / 33 - 4, column c = 4 * (i % 33) - 4 */
+#define P2_CSLOTS (2 * 12 * 17)         /* chroma: plane i / 204, row (i % 204) / 17 - 4, column 4 * (i % 17) - 4 */
+__device__ __forceinline__ bool p2_slot(const FrameDev &F, int i, bool chroma, int x0, int y, int n, int *pl, int *r, int *c, size_t *goff)
+{
+    if (!chroma) {
+        if (i >= P2_LSLOTS) return false;
+        *pl = 0; *r = i / 33 - 4; *c = 4 * (i % 33) - 4;
+        const int gx = 16 * x0 + *c, gy = 16 * y + *r;
+        if (gx < 0 || gy < 0 || *c >= 16 * n) return false;
+        *goff = (size_t)gy * F.w + gx;
+    } else {
+        if (i >= P2_CSLOTS) return false;
+        const int j = i % 204;
+        *pl = 1 + i / 204; *r = j / 17 - 4; *c = 4 * (j % 17) - 4;
+        const int gx = 8 * x0 + *c, gy = 8 * y + *r;
+        if (gx < 0 || gy < 0 || *c >= 8 * n) return false;
+        *goff = (size_t)gy * (F.w >> 1) + gx;
+    }
+    return true;
+}
+__device__ __forceinline__ void p2_unit_load(const FrameDev &F, P2Unit *U, int x0, int y, int n)
+{
+    const int lane = LANE(), xy0 = y * F.mb_w + x0;
+    /* every load first, then the stores to LDS: one round trip for the run */
+    uint32_t vl[11], vc[7], vr[8];
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        int pl, r, c; size_t o;
+        vl[t] = p2_slot(F, lane + 64 * t, false, x0, y, n, &pl, &r, &c, &o) ? NB_LD32(F.rec[0] + o) : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        int pl, r, c; size_t o;
+        vc[t] = 0u;
+        if (p2_slot(F, lane + 64 * t, true, x0, y, n, &pl, &r, &c, &o)) vc[t] = NB_LD32((pl == 2 ? F.rec[2] : F.rec[1]) + o);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int i = lane + 64 * t, k = i / 59, w = i - 59 * k;
+        vr[t] = (i < 8 * 59 && k < n) ? ((const uint32_t *)&F.rec_mb[xy0 + k])[w] : 0u;
+    }
+    int cb = 0, mf = 1, n1 = 0;
+    if (lane < n) { cb = F.car_base ? F.car_base[xy0 + lane] : 0; mf = F.mbflip ? (int)F.mbflip[xy0 + lane] : 1; n1 = (int)F.nnz[xy0 + lane]; }
+    unsigned tn = 0, ln = 0; uint32_t tm = 0, lm = 0; int tr = 0, lr = 0;
+    const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
+    if (lane < 4 * n && y > 0) {          /* lane = 4 k + j: block j of the bottom row of the macroblock above macroblock k */
+        const int k = lane >> 2, j = lane & 3, fx = 4 * (x0 + k) + j, fy = 4 * y - 1;
+        tn = (unsigned)NB_LD16(&F.nnz[xy0 + k - F.mb_w]); tm = NB_LD32(F.mv + 2 * (fy * s4 + fx)); tr = (int)NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]);
+    }
+    if (lane >= 32 && lane < 36 && x0 > 0) {      /* block (3, j) of the macroblock left of the run */
+        const int j = lane - 32, fx = 4 * x0 - 1, fy = 4 * y + j;
+        ln = (unsigned)NB_LD16(&F.nnz[xy0 - 1]); lm = NB_LD32(F.mv + 2 * (fy * s4 + fx)); lr = (int)NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]);
+    }
+    PCAMV_WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        int pl, r, c; size_t o;
+        if (p2_slot(F, lane + 64 * t, false, x0, y, n, &pl, &r, &c, &o)) *(uint32_t *)&U->ty[r + 4][c + 4] = vl[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        int pl, r, c; size_t o;
+        if (p2_slot(F, lane + 64 * t, true, x0, y, n, &pl, &r, &c, &o)) *(uint32_t *)&U->tc[pl - 1][r + 4][c + 4] = vc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int i = lane + 64 * t;
+        if (i < 8 * 59) ((uint32_t *)U->rec)[i] = vr[t];
+    }
+    if (lane < 8) { U->car_base[lane] = cb; U->mbflip[lane] = mf; U->nnz1[lane] = n1; }
+    if (lane < 32) { U->t_mv[lane >> 2][lane & 3] = tm; U->t_ref[lane >> 2][lane & 3] = tr; if ((lane & 3) == 0) U->t_nnz[lane >> 2] = tn; }
+    if (lane >= 32 && lane < 36) { U->l_mv[lane - 32] = lm; U->l_ref[lane - 32] = lr; if (lane == 32) U->l_nnz = ln; }
+    PCAMV_WAVE_SYNC();
+}
+/* a reconstructed macroblock (L->pred) into its place in the tile */
+__device__ __forceinline__ void p2_put_mb(P2Unit *U, const MBLocal *L, int k)
+{
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+    *(uint32_t *)&U->ty[(lane >> 2) + 4][16 * k + 4 + 4 * (lane & 3)] = lds4(L->pred + (lane >> 2) * 16 + (lane & 3) * 4);
+    if (lane < 32) *(uint32_t *)&U->tc[lane >> 4][((lane & 15) >> 1) + 4][8 * k + 4 + 4 * (lane & 1)] = lds4(L->pred + 256 + ((lane & 15) >> 1) * 16 + (lane >> 4) * 8 + (lane & 1) * 4);
+    PCAMV_WAVE_SYNC();
+}
+/* the loop filter of macroblock k of the run, in the tile (what mbk_deblock does in its staging area; same strengths, same arithmetic) */
+__device__ __forceinline__ void mbk_deblock_unit(const FrameDev &F, P2Unit *U, const MBLocal *Lo, int k, int mx, int my)
+{
+    uint8_t (*sbs)[4][4] = U->sbs;
+    const int lane = LANE();
+    const int type = Lo->i_type, qp = F.qp;
+    const int qp_thresh = 15 - (F.chroma_qp_offset > 0 ? F.chroma_qp_offset : 0);
+    const int edge_end = (type == PCAMV_P_SKIP || qp <= qp_thresh) ? 1 : 4;
+    const int no_sub8x8 = type != PCAMV_P_8x8 || !(F.inter & PCAMV_ANALYSE_PSUB8x8);
+    PCAMV_WAVE_SYNC();
+    if (lane < 32) {
+        const int dir = lane >> 4, edge = (lane >> 2) & 3, i = lane & 3;
+        int bs = 0;
+        const bool on = edge < edge_end && !(edge == 0 && (dir ? my == 0 : mx == 0));
+        if (on) {
+            const int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
+            const int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
+            const int bi = (x & 1) + 2 * (y & 1) + 4 * (x >> 1) + 8 * (y >> 1), bn = (xn & 1) + 2 * (yn & 1) + 4 * (xn >> 1) + 8 * (yn >> 1);
+            const int c8a = SCAN8_0 + x + 8 * y, c8b = SCAN8_0 + xn + 8 * yn;
+            const unsigned nz_a = (unsigned)Lo->nnz_mask;
+            const unsigned nz_b = edge ? (unsigned)Lo->nnz_mask : dir ? U->t_nnz[k] : U->l_nnz;
+            const uint32_t wa = NB_PACK16(Lo->cmv[c8a][0], Lo->cmv[c8a][1]);
+            const uint32_t wb = edge ? NB_PACK16(Lo->cmv[c8b][0], Lo->cmv[c8b][1]) : dir ? U->t_mv[k][i] : U->l_mv[i];
+            const int ra = (int)Lo->cref[c8a];
+            const int rb = edge ? (int)Lo->cref[c8b] : dir ? U->t_ref[k][i] : U->l_ref[i];
+            if (((nz_a >> bi) & 1) || ((nz_b >> bn) & 1)) bs = 2;
+            else if (!(edge & no_sub8x8)) {
+                const int a0 = (int16_t)(wa & 0xffff), a1 = (int16_t)(wa >> 16), b0 = (int16_t)(wb & 0xffff), b1 = (int16_t)(wb >> 16);
+                if (ra != rb || iabs(a0 - b0) >= 4 || iabs(a1 - b1) >= 4) bs = 1;
+                bs |= 0x10;
+            }
+        }
+        sbs[dir][edge][i] = (uint8_t)bs;
+    }
+    __syncthreads();
+    {
+        const int dir = (lane >> 4) & 1, edge = (lane >> 2) & 3, i = lane & 3;
+        int bs = sbs[dir][edge][i];
+        const int prev = i ? sbs[dir][edge][i - 1] & 0xf : 0;
+        __syncthreads();
+        if (lane < 32) {
+            if ((bs & 0x10) && (i & no_sub8x8) && prev != 2) bs = prev;
+            sbs[dir][edge][i] = (uint8_t)(bs & 0xf);
+        }
+    }
+    __syncthreads();
+    const int qpc = F.chroma_qp;
+    const int alpha = dbk_alpha_dev[qp], beta = dbk_beta_dev[qp], calpha = dbk_alpha_dev[qpc], cbeta = dbk_beta_dev[qpc];
+    const int tl1 = dbk_tc0_dev[qp][0], tl2 = dbk_tc0_dev[qp][1], tl3 = dbk_tc0_dev[qp][2];
+    const int tc1 = dbk_tc0_dev[qpc][0], tc2 = dbk_tc0_dev[qpc][1], tc3 = dbk_tc0_dev[qpc][2];
+    for (int dir = 0; dir < 2; dir++)
+        for (int edge = 0; edge < 4; edge++) {
+            const uint32_t any = *(const uint32_t *)sbs[dir][edge];
+            if (any) {
+                if (lane < 16 && alpha && beta) {
+                    const int bs = sbs[dir][edge][lane >> 2];
+                    if (bs) {
+                        const int tc0 = bs == 1 ? tl1 : bs == 2 ? tl2 : tl3;
+                        uint8_t *q = dir == 0 ? &U->ty[lane + 4][16 * k + 4 * edge + 4] : &U->ty[4 * edge + 4][16 * k + lane + 4];
+                        const int xs = dir == 0 ? 1 : P2_TW;
+                        const int p2 = q[-3 * xs], p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs], q2 = q[2 * xs];
+                        if (iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta) {
+                            int tc = tc0;
+                            if (iabs(p2 - p0) < beta) { q[-2 * xs] = (uint8_t)(p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0)); tc++; }
+                            if (iabs(q2 - q0) < beta) { q[xs] = (uint8_t)(q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0)); tc++; }
+                            const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+                            q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
+                        }
+                    }
+                } else if (lane >= 16 && lane < 32 && !(edge & 1) && calpha && cbeta) {
+                    const int pl = (lane - 16) >> 3, l = (lane - 16) & 7, bs = sbs[dir][edge][l >> 1];
+                    if (bs) {
+                        const int tc = (bs == 1 ? tc1 : bs == 2 ? tc2 : tc3) + 1;
+                        uint8_t *q = dir == 0 ? &U->tc[pl][l + 4][8 * k + 2 * edge + 4] : &U->tc[pl][2 * edge + 4][8 * k + l + 4];
+                        const int xs = dir == 0 ? 1 : P2_CW;
+                        const int p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs];
+                        if (iabs(p0 - q0) < calpha && iabs(p1 - p0) < cbeta && iabs(q1 - q0) < cbeta) {
+                            const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
+                            q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    /* this macroblock's right column of 4x4 blocks is the next one's left neighbour */
+    if (lane < 4) { const int c8 = SCAN8_0 + 3 + 8 * lane; U->l_mv[lane] = NB_PACK16(Lo->cmv[c8][0], Lo->cmv[c8][1]); U->l_ref[lane] = (int)Lo->cref[c8]; }
+    if (lane == 0) U->l_nnz = (unsigned)Lo->nnz_mask;
+    PCAMV_WAVE_SYNC();
+}
+/* the tile back to the frame: the run's rows 0..15 with the four columns left of it (the left neighbour's, touched by the first
+ * macroblock's left edge), and the four rows above it */
+__device__ __forceinline__ void p2_unit_store(const FrameDev &F, P2Unit *U, int x0, int y, int n)
+{
+    const int lane = LANE();
+    PCAMV_WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < 11; t++) {
+        int pl, r, c; size_t o;
+        if (p2_slot(F, lane + 64 * t, false, x0, y, n, &pl, &r, &c, &o) && (r < 0 ? c >= 0 : true)) NB_ST32(F.rec[0] + o, *(const uint32_t *)&U->ty[r + 4][c + 4]);
+    }
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        int pl, r, c; size_t o;
+        if (p2_slot(F, lane + 64 * t, true, x0, y, n, &pl, &r, &c, &o) && (r < 0 ? c >= 0 : true)) NB_ST32((pl == 2 ? F.rec[2] : F.rec[1]) + o, *(const uint32_t *)&U->tc[pl - 1][r + 4][c + 4]);
+    }
+}
 #ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64) k_deblock_diag(const FrameDev *__restrict__ Fs, int d)
 {
@@ -587,7 +795,7 @@ __device__ __forceinline__ bool mbk_search_spec(const FrameDev &F, MBLocal *L, A
 /* the queue protocol, shared by the two persistent kernels; MODE 0: search -> publish -> reconstruction + RCA,
  * MODE 1: pass 2 + loop filter of the macroblock -> publish */
 template <int MODE, int TESA>
-__device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const FlowDev &fl, MBLocal &L, Analysis *Ap, DeblockLDS *Dp)
+__device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const FlowDev &fl, MBLocal &L, Analysis *Ap, P2Unit *Up)
 {
     const int lane = LANE();
     /* home queue = this wave's XCD (speed only: the GOPs of one queue are then searched through one L2
@@ -650,15 +858,15 @@ __device__ __forceinline__ void flow_loop(const FrameDev *__restrict__ Fs, const
         if (MODE == 0 && (TESA & 4)) { if (!mbk_search_spec<TESA>(F, &L, Ap, x, y, fl, g, item)) break; }
         else if (MODE == 0) mbk_search<TESA>(F, &L, Ap, x, y);
         else {
-            for (int k = 0; k < fl.unit; k++) {
-                const int mx = fl.unit * x + k;
-                if (mx >= F.mb_w) break;
-                if (k) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the filter of the macroblock to the left changed pixels, and its second pass stored motion, that this one reads */
-                const DbkPre pre = dbk_pre_issue(F, mx, y);                    /* the neighbours' side of the filter's input: in flight while the second pass runs */
-                mbk_pass2(F, &L, mx, y, 0);
-                PCAMV_WAVE_SYNC();
-                mbk_deblock(F, Dp, mx, y, &L, &pre);    /* the unfiltered macroblock goes from LDS to LDS, not through memory */
+            const int x0 = fl.unit * x, n = imin(fl.unit, F.mb_w - x0);
+            p2_unit_load(F, Up, x0, y, n);
+            for (int k = 0; k < n; k++) {
+                P2Pre pre;
+                pre.r = &Up->rec[k]; pre.base = Up->car_base[k]; pre.any_flip = Up->mbflip[k]; pre.nnz1 = Up->nnz1[k]; pre.drain = k > 0;
+                if (mbk_pass2(F, &L, x0 + k, y, 0, &pre)) p2_put_mb(Up, &L, k);
+                mbk_deblock_unit(F, Up, &L, k, x0 + k, y);
             }
+            p2_unit_store(F, Up, x0, y, n);
         }
         PROF_ADD(MODE ? 14 : 1, t_s);
         const unsigned long long t_p = PROF_T();
@@ -748,7 +956,7 @@ int pcamv_flow_rd_waves_per_cu_spec4(void);
  * filter reads its neighbourhood with agent-scope loads (NB_LD*).  (With an agent-scope release + acquire per
  * macroblock this was slower than one launch per anti-diagonal: 245 vs 176 ms per closed-loop step at G=256.) */
 #ifndef PCAMV_PASS2_OCC
-#define PCAMV_PASS2_OCC 6         /* waves per SIMD the second-pass kernel's registers are held to (its LDS allows eight) */
+#define PCAMV_PASS2_OCC 4         /* waves per SIMD the second-pass kernel's registers are held to (its LDS -- the tile of a run of macroblocks -- allows four) */
 #endif
 #ifdef PCAMV_MAIN_TU
 static __global__ void __launch_bounds__(64, PCAMV_PASS2_OCC) k_pass2_deblock_flow(const FrameDev *__restrict__ Fs, FlowDev fl)
@@ -757,8 +965,8 @@ static __global__ void __launch_bounds__(64, PCAMV_PASS2_OCC) k_pass2_deblock_fl
      * of 8.9 KB per wave with the filter's staging area, so the CU holds the six waves per SIMD the kernel's 83 VGPRs allow -- it
      * waits for memory three quarters of its time, more waves in flight is what it can use */
     __shared__ __attribute__((aligned(16))) uint8_t Lraw[PCAMV_PASS2_LDS];
-    __shared__ DeblockLDS D;
-    flow_loop<1, 0>(Fs, fl, *reinterpret_cast<MBLocal *>(Lraw), nullptr, &D);
+    __shared__ __attribute__((aligned(16))) P2Unit U;
+    flow_loop<1, 0>(Fs, fl, *reinterpret_cast<MBLocal *>(Lraw), nullptr, &U);
 }
 #endif
 

@@ -210,20 +210,26 @@ PCAMV_DEV void mbk_rca_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy
  * dependency as the search. */
 /* store_rec = 0: the loop filter that follows in the same wave takes the reconstruction from L->pred and writes the
  * filtered macroblock itself */
-PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int store_rec = 1)
+/* unit: the second-pass kernel takes a run of macroblocks of a row per task and loads what they need of memory ONCE, together (k_pass2_deblock_flow,
+ * P2Unit): the record, the index of the first carrier, "any carrier flipped", the first pass' non-zero flags come from there, and the pixels
+ * of a macroblock the embedding left alone are already where the loop filter works -- nothing is loaded here then.  Returns 1 when the macroblock
+ * was reconstructed anew (L->pred holds its pixels), 0 when the first pass' reconstruction stands. */
+struct P2Pre { const pcamv_mb_t *r; int base, any_flip, nnz1, drain; };
+PCAMV_DEV int mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int store_rec = 1, const P2Pre *unit = nullptr)
 {
     const int xy = mb_y * F.mb_w + mb_x;
     /* the macroblock's record (59 words) and the index of its first carrier come in with ONE memory round trip, into storage that is
      * idle in this pass (the candidate costs); read field by field from memory, type / partition / sub-partitions / used / MVs were a
      * dozen dependent round trips at the head of a task that is only ~3 k instructions long */
-    pcamv_mb_t *r = (pcamv_mb_t *)L->ccost;
+    const pcamv_mb_t *r = unit ? unit->r : (const pcamv_mb_t *)L->ccost;
     PCAMV_WAVE_SYNC();
 #ifndef PCAMV_HOST_EMU
     /* asked for in the same round trip as the record, before anything is known about the macroblock: "is any carrier of it flipped" and
      * its first-pass reconstruction (used when the macroblock turns out to be what the first pass made, below: 7 of 8) */
     uint32_t pre_y = 0, pre_c = 0;
     int any_flip = 1;
-    {
+    if (unit) any_flip = unit->any_flip;
+    else {
         const int lane = LANE();
         if (F.rec_is_pass1) {
             pre_y = *(const uint32_t *)(F.rec[0] + (size_t)(mb_y * 16 + (lane >> 2)) * F.w + mb_x * 16 + (lane & 3) * 4);
@@ -234,11 +240,17 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
 #else
     const int any_flip = 1;
 #endif
-    FOR_CAND(i, (int)(sizeof(pcamv_mb_t) / 4) + 1) {
-        if (i < (int)(sizeof(pcamv_mb_t) / 4)) ((uint32_t *)r)[i] = ((const uint32_t *)&F.rec_mb[xy])[i];
-        else L->ccost[191] = F.car_base ? F.car_base[xy] : 0;
+    if (!unit) {
+        FOR_CAND(i, (int)(sizeof(pcamv_mb_t) / 4) + 1) {
+            if (i < (int)(sizeof(pcamv_mb_t) / 4)) ((uint32_t *)L->ccost)[i] = ((const uint32_t *)&F.rec_mb[xy])[i];
+            else L->ccost[191] = F.car_base ? F.car_base[xy] : 0;
+        }
     }
     PCAMV_WAVE_SYNC();
+#ifndef PCAMV_HOST_EMU
+    /* (a run of macroblocks per task: the skip prediction reads the left neighbour's final motion from memory, where this wave stored it a moment ago) */
+    if (unit && unit->drain && r->i_type == PCAMV_P_SKIP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
     L->i_type = r->i_type; L->i_partition = r->i_partition;
     for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
@@ -251,7 +263,7 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
     } else {
         int *slots = L->slots;
         const int n = carrier_slots(L->i_type, L->i_partition, L->sub_part, r->used, slots);
-        const int base = L->ccost[191];
+        const int base = unit ? unit->base : L->ccost[191];
         PCAMV_WAVE_SYNC();
         /* its carriers' flip flags: one more round trip, for the macroblocks that have a flipped carrier at all */
         if (PCAMV_RFL(any_flip)) { FOR_CAND(j, n) L->cxy[j] = F.flip ? (uint32_t)(F.flip[base + j] == 1) : 0u; }
@@ -271,12 +283,13 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
     /* A macroblock whose motion is what the first pass decided -- no carrier of it flipped; skipped with the same skip prediction --
      * reconstructs to what the first pass stored (same type, motion, source, reference and quantiser): pixels and non-zero flags
      * are taken from there instead of being made again.  (~7 of 8 macroblocks at half a bit per carrier.) */
-    if (same && F.rec_is_pass1) {
+    const int reuse = same && F.rec_is_pass1;
+    if (reuse) {
 #ifdef PCAMV_HOST_EMU
         L->nnz_mask = F.nnz[xy];
 #else
-        L->nnz_mask = rfl((int)F.nnz[xy]);
-        {   /* (the layout of prim_store_rec) */
+        L->nnz_mask = unit ? unit->nnz1 : rfl((int)F.nnz[xy]);
+        if (!unit) {   /* (the layout of prim_store_rec) */
             const int lane = LANE();
             PCAMV_WAVE_SYNC();
             sts4(L->pred + (lane >> 2) * 16 + (lane & 3) * 4, pre_y);
@@ -305,6 +318,7 @@ PCAMV_DEV void mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int 
         NB_ST16(&F.ref8[b8], 0); NB_ST16(&F.ref8[b8 + s8], 0);
         NB_ST16(&F.nnz[xy], L->nnz_mask);
     }
+    return !reuse;
 }
 
 PCAMV_DEV void mbk_encode(const FrameDev &F, MBLocal *L, Analysis *a, int xy)
