@@ -806,7 +806,7 @@ def test_speculative_chain_with_few_waves(pc, monkeypatch, waves):
 
 @pytest.mark.parametrize("unit", [3, 8])
 def test_pass2_task_sizes_match_oracle(pc, monkeypatch, unit):
-    """the second pass takes `unit` macroblocks of a row per queue task (8 by default from 1024 GOPs in flight on -- more than a
+    """the second pass takes `unit` macroblocks of a row per queue task (8 by default from 256 GOPs in flight on -- more than a
     test can afford, so the size is forced here): rows of 22 macroblocks = tasks of 8 + 8 + 6 and 3 x 7 + 1, both RD levels"""
     monkeypatch.setenv("PCAMV_PASS2_UNIT", str(unit))
     assert _closed_loop_vs_oracle(pc, 352, 288, "hex", 5, 30, 3, 2, 81) > 0

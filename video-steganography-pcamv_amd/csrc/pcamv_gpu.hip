@@ -250,8 +250,10 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
         /* the second pass can take `unit` macroblocks of a row per task (PCAMV_PASS2_UNIT; the dependency graph is the
          * same on the coarser grid).  Measured at G=256: 115.1 / 114.7 / 116.9 / 122.6 ms per step for 1 / 2 / 4 / 8 --
          * its queue traffic is not what bounds it any more.  With thousands of GOPs in flight it is again: 4096 GOPs 2300 / 2277 /
-         * 2264 / 2253 ms per step.  Default: 8 from 1024 GOPs on, else 1.  Same buffers: the two kernels never overlap. */
-        { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : (n >= 1024 ? 8 : 1);
+         * 2264 / 2253 ms per step.  Round 3: a task's macroblocks are one LDS tile (P2Unit: one memory round trip, whole cache lines), which is
+         * what the run is for now -- 1080p, ms per step for 1 / 8: 1 GOP 316 / 319, 256 GOPs 354 / 353, 512 GOPs 391 / 382, 4096 GOPs: the
+         * kernel alone 106 (macroblock by macroblock) -> 65.  Default: 8 from 256 GOPs on, else 1.  Same buffers: the two kernels never overlap. */
+        { const char *u = getenv("PCAMV_PASS2_UNIT"); const int unit = u && atoi(u) >= 1 && atoi(u) <= 8 ? atoi(u) : (n >= 256 ? 8 : 1);
           b->fl2 = b->fl; b->fl2.unit = unit; b->fl2.raster = 0; b->fl2.spec = 0; b->fl2.mb_w = (F.mb_w + unit - 1) / unit; b->fl2.n_mb = b->fl2.mb_w * F.mb_h;
           b->fl2.total = (unsigned)n * (unsigned)b->fl2.n_mb;
           unsigned qb2 = 0;
