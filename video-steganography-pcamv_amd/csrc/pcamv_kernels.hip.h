@@ -221,60 +221,7 @@ __device__ static const int8_t dbk_tc0_dev[52][3] = {
 struct DeblockLDS { uint8_t sy[20][24]; uint8_t sc[2][12][16]; uint8_t sbs[2][4][4]; };
 /* Lo: the MBLocal pass 2 of this macroblock has just run in (same wave): its unfiltered reconstruction (pred), type, final
  * motion and non-zero flags are taken from there; nullptr: everything is in memory like the neighbours' */
-/* What the filter of a macroblock reads of its neighbours -- the four pixels to the left of and above it, and for the two outer edges the
- * neighbours' non-zero flags, motion and reference -- depends on (x, y) only: in the second-pass kernel it is asked for BEFORE the
- * macroblock's own second pass, in the same memory round trip as its record, and handed to mbk_deblock in registers.
- * Slot idx of the border: 0..19 luma rows -4..-1 (5 dwords each, columns -4..12), 20..35 luma column -4 of rows 0..15,
- * 36..59 chroma rows -4..-1 (2 planes x 4 rows x 3 dwords), 60..75 chroma column -4 of rows 0..7 (2 planes). */
-struct DbkPre { uint32_t a, b, wb; unsigned nzb; int rb; };
-__device__ __forceinline__ bool dbk_border_slot(int idx, int *plane, int *r, int *c)
-{
-    if (idx < 20) { *plane = 0; *r = idx / 5 - 4; *c = (idx % 5) * 4 - 4; return true; }
-    if (idx < 36) { *plane = 0; *r = idx - 20; *c = -4; return true; }
-    if (idx < 60) { const int j = idx - 36, k = j % 12; *plane = 1 + j / 12; *r = k / 3 - 4; *c = (k % 3) * 4 - 4; return true; }
-    if (idx < 76) { const int j = idx - 60; *plane = 1 + (j >> 3); *r = j & 7; *c = -4; return true; }
-    return false;
-}
-__device__ __forceinline__ uint32_t dbk_border_load(const FrameDev &F, int idx, int mx, int my)
-{
-    int pl, r, c;
-    if (!dbk_border_slot(idx, &pl, &r, &c)) return 0u;
-    const int gx = (pl ? 8 : 16) * mx + c, gy = (pl ? 8 : 16) * my + r;
-    if (gx < 0 || gy < 0) return 0u;
-    /* (two-way choices only: a three-way choice among members of the by-value descriptor becomes an indexed access, and the whole
-     * descriptor then lives in scratch -- DESIGN 5) */
-    if (pl == 0) return NB_LD32(F.rec[0] + (size_t)gy * F.w + gx);
-    return NB_LD32((pl == 2 ? F.rec[2] : F.rec[1]) + (size_t)gy * (F.w >> 1) + gx);
-}
-__device__ __forceinline__ void dbk_border_store(DeblockLDS *D, int idx, int mx, int my, uint32_t v)
-{
-    int pl, r, c;
-    if (!dbk_border_slot(idx, &pl, &r, &c)) return;
-    if ((pl ? 8 : 16) * mx + c < 0 || (pl ? 8 : 16) * my + r < 0) return;
-    if (pl == 0) *(uint32_t *)&D->sy[r + 4][c + 4] = v; else *(uint32_t *)&D->sc[pl - 1][r + 4][c + 4] = v;
-}
-__device__ __forceinline__ DbkPre dbk_pre_issue(const FrameDev &F, int mx, int my)
-{
-    DbkPre P;
-    const int lane = LANE(), xy = my * F.mb_w + mx;
-    P.a = dbk_border_load(F, lane, mx, my);
-    P.b = lane < 12 ? dbk_border_load(F, 64 + lane, mx, my) : 0u;
-    P.nzb = 0; P.wb = 0; P.rb = 0;
-    if (lane < 32 && ((lane >> 2) & 3) == 0) {          /* the lanes that make the strengths of the left / upper macroblock edge (same mapping as in mbk_deblock) */
-        const int dir = lane >> 4, i = lane & 3;
-        if (!(dir ? my == 0 : mx == 0)) {
-            const int x = dir == 0 ? 0 : i, y = dir == 0 ? i : 0;
-            const int nxy = dir ? xy - F.mb_w : xy - 1;
-            const int s4 = 4 * F.mb_w, s8 = 2 * F.mb_w;
-            const int fx = 4 * mx + x, fy = 4 * my + y, fxn = dir == 0 ? fx - 1 : fx, fyn = dir == 0 ? fy : fy - 1;
-            P.nzb = (unsigned)NB_LD16(&F.nnz[nxy]);
-            P.wb = NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
-            P.rb = (int)NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]);
-        }
-    }
-    return P;
-}
-__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my, const MBLocal *Lo = nullptr, const DbkPre *P = nullptr)
+__device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, int mx, int my, const MBLocal *Lo = nullptr)
 {
     const uint8_t *own = Lo ? Lo->pred : nullptr;
     uint8_t (*sy)[24] = D->sy;              /* rows / cols -4..15 of the macroblock at [r + 4][c + 4] */
@@ -283,16 +230,15 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
     const int lane = LANE(), xy = my * F.mb_w + mx, W = F.w, CW = F.w >> 1;
     const int gx = 16 * mx, gy = 16 * my, cgx = 8 * mx, cgy = 8 * my;
     /* stage: 20 rows x 5 dwords of luma, 2 x 12 rows x 3 dwords of chroma (nothing outside the picture) */
-    if (P) { dbk_border_store(D, lane, mx, my, P->a); if (lane < 12) dbk_border_store(D, 64 + lane, mx, my, P->b); }
     for (int i = lane; i < 100; i += 64) {
         const int r = i / 5 - 4, c = (i % 5) * 4 - 4;
         if (own && r >= 0 && c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = lds4(own + r * 16 + c);
-        else if (!P && gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = NB_LD32(F.rec[0] + (size_t)(gy + r) * W + gx + c);
+        else if (gy + r >= 0 && gx + c >= 0) *(uint32_t *)&sy[r + 4][c + 4] = NB_LD32(F.rec[0] + (size_t)(gy + r) * W + gx + c);
     }
     for (int i = lane; i < 72; i += 64) {
         const int pl = i / 36, j = i % 36, r = j / 3 - 4, c = (j % 3) * 4 - 4;
         if (own && r >= 0 && c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = lds4(own + 256 + r * 16 + pl * 8 + c);
-        else if (!P && cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
+        else if (cgy + r >= 0 && cgx + c >= 0) *(uint32_t *)&sc[pl][r + 4][c + 4] = NB_LD32((pl ? F.rec[2] : F.rec[1]) + (size_t)(cgy + r) * CW + cgx + c);
     }
     /* boundary strengths */
     const int type = Lo ? Lo->i_type : (int)NB_LD8(&F.mb_type[xy]), qp = F.qp;
@@ -315,12 +261,11 @@ __device__ __forceinline__ void mbk_deblock(const FrameDev &F, DeblockLDS *D, in
             const bool nb_local = Lo && edge;
             const int c8a = SCAN8_0 + x + 8 * y, c8b = SCAN8_0 + xn + 8 * yn;
             const unsigned nz_a = Lo ? (unsigned)Lo->nnz_mask : (unsigned)NB_LD16(&F.nnz[xy]);
-            const bool pre = P && !edge;             /* the neighbour's side of an outer edge came in with dbk_pre_issue */
-            const unsigned nz_b = nb_local ? (unsigned)Lo->nnz_mask : pre ? P->nzb : (unsigned)NB_LD16(&F.nnz[nxy]);
+            const unsigned nz_b = nb_local ? (unsigned)Lo->nnz_mask : (unsigned)NB_LD16(&F.nnz[nxy]);
             const uint32_t wa = Lo ? NB_PACK16(Lo->cmv[c8a][0], Lo->cmv[c8a][1]) : NB_LD32(F.mv + 2 * (fy * s4 + fx));
-            const uint32_t wb = nb_local ? NB_PACK16(Lo->cmv[c8b][0], Lo->cmv[c8b][1]) : pre ? P->wb : NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
+            const uint32_t wb = nb_local ? NB_PACK16(Lo->cmv[c8b][0], Lo->cmv[c8b][1]) : NB_LD32(F.mv + 2 * (fyn * s4 + fxn));
             const int ra = Lo ? (int)Lo->cref[c8a] : (int)NB_LD8(&F.ref8[(fy >> 1) * s8 + (fx >> 1)]);
-            const int rb = nb_local ? (int)Lo->cref[c8b] : pre ? P->rb : (int)NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]);
+            const int rb = nb_local ? (int)Lo->cref[c8b] : (int)NB_LD8(&F.ref8[(fyn >> 1) * s8 + (fxn >> 1)]);
             if (((nz_a >> bi) & 1) || ((nz_b >> bn) & 1)) bs = 2;
             else if (!(edge & no_sub8x8)) {
                 const int a0 = (int16_t)(wa & 0xffff), a1 = (int16_t)(wa >> 16), b0 = (int16_t)(wb & 0xffff), b1 = (int16_t)(wb >> 16);
