@@ -320,6 +320,9 @@ def test_embedding_edge_cases(pc):
     from pcamv_amd.synth import make_clip
     W, H = 176, 144
     clip = make_clip(W, H, 2, seed=4, static_cols=48)
+    # (the sub-matrix widths beyond the tables draw their columns from a generator that is process-wide in the reference and in the
+    # oracle, per context in the library: a fresh context goes with the generator's initial state, whatever ran before in this process)
+    orc.lib().orc_stc_lcg_reset(1)
     p = _params(pc, W, H, 1, 5, 0x10, 64, tscale=0)
     enc = pc.Encoder(p)
     o = orc.Oracle(orc.make_params(W, H, mv_range=64, tscale=0))
@@ -357,6 +360,16 @@ def test_embedding_edge_cases(pc):
     e = enc.embed_pframe(0.5)
     assert e["n"] == 0 and e["m"] == 0 and e["num_flip"] == 0
     enc.close(); o.close()
+
+
+def test_stc_forward_with_four_states_per_thread(pc, monkeypatch):
+    """the forward Viterbi of the embedding stage runs 4 trellis states per thread (4 waves per frame) from 1024 GOPs in flight on, 2
+    below -- more than a test can afford, so the instance is forced here: the same cover / rho / stego / flip vectors and payloads,
+    tabulated sub-matrix widths and generated ones, short messages"""
+    monkeypatch.setenv("PCAMV_STC_STATES", "4")
+    test_full_pipeline_matches_oracle_and_extracts(pc, (176, 144, "hex", 5, 0x10, 0.5))
+    test_full_pipeline_matches_oracle_and_extracts(pc, (352, 288, "dia", 3, 0x10, 35.0))
+    test_embedding_edge_cases(pc)
 
 
 def test_open_rejects_unsupported(pc):
@@ -616,6 +629,7 @@ def _closed_loop_vs_oracle(pc, W, H, me, subme, qp, n_gops, steps, seed0, emrate
     import orc
     from pcamv_amd.synth import make_clip
     clips = [make_clip(W, H, steps + 1, seed=seed0 + g, static_cols=statics[g % len(statics)], noise=noise) for g in range(n_gops)]
+    orc.lib().orc_stc_lcg_reset(1)          # fresh contexts: the column generator's initial state on both sides (it is process-wide in the oracle)
     dev = torch.device("cuda", 0)
     d = [[[torch.from_numpy(np.ascontiguousarray(pl)).to(dev) for pl in fr] for fr in clip] for clip in clips]
     mvr = pc.level_mv_range(W, H)

@@ -38,7 +38,7 @@ struct pcamv_batch {
     int ev_n, ev_head;
     double t_search_ms; int t_search_launches;
     /* dataflow schedule (k_analyse_flow): queue + dependency counters, one persistent launch per step */
-    int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo, rd_spec;
+    int sched_flow, flow_waves, flow2_waves, closed_loop, rd_lo, rd_spec, stc_ns;
     int b_mbrd, b_tesa;         /* instance of the analysis kernel the batch's contexts need (fixed at creation) */
     unsigned *d_flow;
     FlowDev fl, fl2;          /* queue descriptors of the analysis and of the second pass */
@@ -191,6 +191,7 @@ extern "C" int pcamv_gpu_batch_create(pcamv_ctx_t *const *ctxs, int n, pcamv_bat
      * the default is the dataflow kernel.  Both are the same per-macroblock code. */
     const char *sched = getenv("PCAMV_SCHED");
     b->sched_flow = !(sched && !strcmp(sched, "diag")) && F.n_mb <= 65535 && n <= 65535;
+    { const char *v = getenv("PCAMV_STC_STATES"); b->stc_ns = v && (atoi(v) == 2 || atoi(v) == 4) ? atoi(v) : (n >= 1024 ? 4 : 2); }      /* trellis states per thread of the forward Viterbi */
     if (e == hipSuccess && b->sched_flow) {
         const size_t total = (size_t)n * F.n_mb;
         e = dalloc(&b->d_flow, FLOW_CTR_WORDS + 2 * total + (size_t)FLOW_RDONE_STRIDE * n);
@@ -575,7 +576,10 @@ static int batch_launch(pcamv_batch *b, int what, hipStream_t st, int timed)
     if (what & 4) {
         hipLaunchKernelGGL(k_embed_prepare, dim3(G), dim3(1024), 0, st, dE);
         /* 2 trellis states per thread: measured 3.25 / 2.89 / 2.90 ms per 1080p frame for 1 / 2 / 4 */
-        hipLaunchKernelGGL(k_stc_forward<2>, dim3(G), dim3(512), 0, st, dE);
+        /* (one frame alone: 2 trellis states per thread is the fastest chain; thousands of frames: 4 states per thread = 4 waves per frame, so
+         * that a CU holds eight frames' trellises instead of four and the batch needs half the rounds: 18.6 -> 13.3 ms per 4096-frame step) */
+        if (b->stc_ns == 4) hipLaunchKernelGGL(k_stc_forward<4>, dim3(G), dim3(256), 0, st, dE);
+        else hipLaunchKernelGGL(k_stc_forward<2>, dim3(G), dim3(512), 0, st, dE);
         hipLaunchKernelGGL(k_stc_backward, dim3(G), dim3(64), 0, st, dE);
         hipLaunchKernelGGL(k_mb_flips, dim3((F.n_mb + 255) / 256, G), dim3(256), 0, st, dE);
     }
