@@ -119,6 +119,7 @@ PCAMV_DEV int predict_mv_ref16x16(const FrameDev &F, MBLocal *L, int (*mvc)[2])
 
 /* lite: only what the reconstruction of a macroblock with known MVs needs (position, MV limits, source pixels) --
  * no neighbour types / motion, no skip prediction (second pass of a macroblock that is not P_SKIP) */
+/* lite = 2: nothing of the neighbours AND no source pixels (the second pass of a macroblock that may turn out to need neither; it loads them itself when it re-encodes) */
 PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int lite = 0, int rd = 0)
 {
     L->mb_x = mb_x; L->mb_y = mb_y; L->mb_xy = mb_y * F.mb_w + mb_x;
@@ -185,7 +186,8 @@ PCAMV_DEV void mb_load(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int li
     L->mv_max_spel[1] = imin(L->mv_max_spel[1], fmv * 4);
     L->mv_min_fpel[1] = (L->mv_min_spel[1] >> 2) + 5;
     L->mv_max_fpel[1] = (L->mv_max_spel[1] >> 2) - 5;
-    if (lite) prim_load_fenc(F, L);
+    if (lite == 2) { }
+    else if (lite) prim_load_fenc(F, L);
     else prim_mb_fetch_store(F, L, rd, pf);         /* source pixels; --subme >= 6: intra neighbours, entropy-coder neighbourhood, context states */
 }
 

@@ -251,7 +251,9 @@ PCAMV_DEV int mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int s
     /* (a run of macroblocks per task: the skip prediction reads the left neighbour's final motion from memory, where this wave stored it a moment ago) */
     if (unit && unit->drain && r->i_type == PCAMV_P_SKIP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP);      /* only a skipped macroblock needs its neighbours (skip prediction) */
+    /* only a skipped macroblock needs its neighbours (skip prediction); the source pixels only a macroblock that is re-encoded (below) */
+    const int defer_fenc = unit != nullptr && r->i_type != PCAMV_P_SKIP;
+    mb_load(F, L, mb_x, mb_y, r->i_type != PCAMV_P_SKIP ? (defer_fenc ? 2 : 1) : 0);
     L->i_type = r->i_type; L->i_partition = r->i_partition;
     for (int i = 0; i < 4; i++) L->sub_part[i] = r->i_sub_partition[i];
     cache_ref_set(L, 0, 0, 4, 4, 0);
@@ -298,6 +300,7 @@ PCAMV_DEV int mbk_pass2(const FrameDev &F, MBLocal *L, int mb_x, int mb_y, int s
         }
 #endif
     } else {
+        if (defer_fenc) prim_load_fenc(F, L);
         mb_encode(F, L);
 #ifdef PCAMV_HOST_EMU
         prim_store_rec(F, L);
