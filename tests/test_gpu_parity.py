@@ -714,6 +714,13 @@ def test_config3_1080p_umh_subme7_closed_loop(pc):
     assert _closed_loop_vs_oracle(pc, 1920, 1088, "umh", 7, 26, 2, 2, 13, statics=(480, 0)) > 4000
 
 
+def test_config3_1080p_second_pass_in_runs_of_eight(pc, monkeypatch):
+    """config 3 with the second pass as the bench runs it: tasks of eight macroblocks of a row, each one tile in LDS (P2Unit) -- at 1080p's
+    own geometry (rows of 120 macroblocks = 15 runs), which the small-picture tests of the run sizes do not have"""
+    monkeypatch.setenv("PCAMV_PASS2_UNIT", "8")
+    assert _closed_loop_vs_oracle(pc, 1920, 1088, "umh", 7, 26, 2, 2, 19, statics=(0, 480)) > 4000
+
+
 def test_config5_2160p_esa(pc):
     """config 5: 3840x2160, exhaustive search, one GOP, one full P frame (32400 macroblocks in one chain)"""
     assert _closed_loop_vs_oracle(pc, 3840, 2160, "esa", 6, 26, 1, 1, 17, statics=(1920,)) > 4000
