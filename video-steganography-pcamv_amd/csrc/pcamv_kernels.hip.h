@@ -496,33 +496,28 @@ __device__ __forceinline__ void mbk_deblock_unit(const FrameDev &F, P2Unit *U, c
     const int alpha = dbk_alpha_dev[qp], beta = dbk_beta_dev[qp], calpha = dbk_alpha_dev[qpc], cbeta = dbk_beta_dev[qpc];
     const int tl1 = dbk_tc0_dev[qp][0], tl2 = dbk_tc0_dev[qp][1], tl3 = dbk_tc0_dev[qp][2];
     const int tc1 = dbk_tc0_dev[qpc][0], tc2 = dbk_tc0_dev[qpc][1], tc3 = dbk_tc0_dev[qpc][2];
+    /* luma lines in lanes 0..15, the chroma lines of the even edges in lanes 16..31 (plane, line), ONE instruction stream for both: the chroma
+     * filter is the luma one without the second-neighbour terms and with tc = tc0 + 1 (deblock_chroma_c vs deblock_luma_c, common/frame.c) */
+    const bool is_c = lane >= 16;
+    const int cpl = (lane - 16) >> 3, cl = (lane - 16) & 7;
+    const int f_alpha = is_c ? calpha : alpha, f_beta = is_c ? cbeta : beta;
     for (int dir = 0; dir < 2; dir++)
         for (int edge = 0; edge < 4; edge++) {
             const uint32_t any = *(const uint32_t *)sbs[dir][edge];
             if (any) {
-                if (lane < 16 && alpha && beta) {
-                    const int bs = sbs[dir][edge][lane >> 2];
+                if (lane < 32 && f_alpha && f_beta && !(is_c && (edge & 1))) {
+                    const int bs = sbs[dir][edge][is_c ? cl >> 1 : lane >> 2];
                     if (bs) {
-                        const int tc0 = bs == 1 ? tl1 : bs == 2 ? tl2 : tl3;
-                        uint8_t *q = dir == 0 ? &U->ty[lane + 4][16 * k + 4 * edge + 4] : &U->ty[4 * edge + 4][16 * k + lane + 4];
-                        const int xs = dir == 0 ? 1 : P2_TW;
+                        const int tc0 = is_c ? (bs == 1 ? tc1 : bs == 2 ? tc2 : tc3) : (bs == 1 ? tl1 : bs == 2 ? tl2 : tl3);
+                        uint8_t *q = is_c ? (dir == 0 ? &U->tc[cpl][cl + 4][8 * k + 2 * edge + 4] : &U->tc[cpl][2 * edge + 4][8 * k + cl + 4])
+                                          : (dir == 0 ? &U->ty[lane + 4][16 * k + 4 * edge + 4] : &U->ty[4 * edge + 4][16 * k + lane + 4]);
+                        const int xs = dir == 0 ? 1 : is_c ? P2_CW : P2_TW;
                         const int p2 = q[-3 * xs], p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs], q2 = q[2 * xs];
-                        if (iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta) {
-                            int tc = tc0;
-                            if (iabs(p2 - p0) < beta) { q[-2 * xs] = (uint8_t)(p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0)); tc++; }
-                            if (iabs(q2 - q0) < beta) { q[xs] = (uint8_t)(q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0)); tc++; }
-                            const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
-                            q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
-                        }
-                    }
-                } else if (lane >= 16 && lane < 32 && !(edge & 1) && calpha && cbeta) {
-                    const int pl = (lane - 16) >> 3, l = (lane - 16) & 7, bs = sbs[dir][edge][l >> 1];
-                    if (bs) {
-                        const int tc = (bs == 1 ? tc1 : bs == 2 ? tc2 : tc3) + 1;
-                        uint8_t *q = dir == 0 ? &U->tc[pl][l + 4][8 * k + 2 * edge + 4] : &U->tc[pl][2 * edge + 4][8 * k + l + 4];
-                        const int xs = dir == 0 ? 1 : P2_CW;
-                        const int p1 = q[-2 * xs], p0 = q[-xs], q0 = q[0], q1 = q[xs];
-                        if (iabs(p0 - q0) < calpha && iabs(p1 - p0) < cbeta && iabs(q1 - q0) < cbeta) {
+                        if (iabs(p0 - q0) < f_alpha && iabs(p1 - p0) < f_beta && iabs(q1 - q0) < f_beta) {
+                            const bool ap = !is_c && iabs(p2 - p0) < f_beta, aq = !is_c && iabs(q2 - q0) < f_beta;
+                            const int tc = is_c ? tc0 + 1 : tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+                            if (ap) q[-2 * xs] = (uint8_t)(p1 + clip3i(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0, tc0));
+                            if (aq) q[xs] = (uint8_t)(q1 + clip3i(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0, tc0));
                             const int delta = clip3i((((q0 - p0) * 4) + (p1 - q1) + 4) >> 3, -tc, tc);
                             q[-xs] = (uint8_t)clip3i(p0 + delta, 0, 255); q[0] = (uint8_t)clip3i(q0 - delta, 0, 255);
                         }
