@@ -186,6 +186,16 @@ struct MBLocal {
 #endif
 };
 #define PCAMV_PASS2_LDS ((int)offsetof(MBLocal, coef))       /* everything up to and including pred */
+/* the second-pass kernel allocates PCAMV_PASS2_LDS bytes of an MBLocal: what it touches must lie below the cut, and two users count on
+ * neighbours staying neighbours (the residual walk's rows run from cxy into ccost; the Hadamard exhaustive search's survivor list and the
+ * intra analysis' picture run from recb on) */
+static_assert(offsetof(MBLocal, pred) + sizeof(((MBLocal *)0)->pred) == offsetof(MBLocal, coef), "pred must end at the second pass' LDS cut");
+static_assert(offsetof(MBLocal, fenc) < PCAMV_PASS2_LDS && offsetof(MBLocal, cmv) < PCAMV_PASS2_LDS && offsetof(MBLocal, cref) < PCAMV_PASS2_LDS &&
+              offsetof(MBLocal, nnz_mask) < PCAMV_PASS2_LDS && offsetof(MBLocal, slots) + sizeof(((MBLocal *)0)->slots) <= PCAMV_PASS2_LDS &&
+              offsetof(MBLocal, ccost) + sizeof(((MBLocal *)0)->ccost) <= PCAMV_PASS2_LDS, "a field the second pass uses lies beyond its LDS");
+static_assert(offsetof(MBLocal, ccost) == offsetof(MBLocal, cxy) + sizeof(((MBLocal *)0)->cxy), "cxy and ccost must be contiguous (cab_residual_walk)");
+static_assert(offsetof(MBLocal, recb0) == offsetof(MBLocal, recb) + 384 && offsetof(MBLocal, pred) == offsetof(MBLocal, recb) + 768 &&
+              offsetof(MBLocal, coef) == offsetof(MBLocal, recb) + 1152, "recb, recb0, pred, the union must be contiguous in this order (TESA_SLOT, L_IFD)");
 /* Storage that is idle while the RD decision runs is reused (no LDS growth): the RCA reference window holds the CABAC
  * context states (slice states, a trial copy of the macroblock-header contexts) and the (bits, next state) table; the RCA
  * reconstruction buffers hold the intra 4x4 analysis' picture (17 rows of 32: row -1 and column -1 are the neighbours);
