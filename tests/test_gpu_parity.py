@@ -807,11 +807,12 @@ def test_bench_regime_matches_oracle(pc, monkeypatch, inst):
     4-waves-per-SIMD build of the RD kernel ("hi": the default run's 4096 chains; "spec4": the speculative one its g_sweep / clip_600
     blocks run at 705..3584 chains), eight per-XCD queues (40 closed GOPs = five chains per queue), fewer waves than chains
     (12: a wave that finishes a macroblock takes whatever chain's next one is ready, queues without a wave of their own are drained
-    by work stealing), the second pass in tasks of 8 macroblocks; three closed-loop steps; of EVERY GOP the records, the context states
+    by work stealing), the second pass in tasks of 8 macroblocks (one LDS tile each), the embedding stage's forward pass at 4 trellis states per thread; three closed-loop steps; of EVERY GOP the records, the context states
     after every macroblock, the embedding vectors, the deblocked planes and the payload back out of the final motion vectors."""
     monkeypatch.setenv("PCAMV_RD_INSTANCE", inst)
     monkeypatch.setenv("PCAMV_PASS2_UNIT", "8")
     monkeypatch.setenv("PCAMV_FLOW_WAVES", "12")
+    monkeypatch.setenv("PCAMV_STC_STATES", "4")          # the forward Viterbi as thousands of frames in flight run it
     assert _closed_loop_vs_oracle(pc, 352, 288, "umh", 7, 26, 40, 3, 171, hashes=True) > 0
 
 
